@@ -1,0 +1,154 @@
+/*
+ * rag_hip.h -- C ABI of librag_hip.so, the MI355X (gfx950) implementation of the
+ * dense-retrieval hot path of llano1025/rAG.
+ *
+ * Every entry point takes plain pointers and sizes, returns an int status
+ * (RAG_OK = 0) and leaves a message for rag_last_error() on failure.  Each
+ * declaration names the reference interface it stands in for (paths relative to
+ * the reference tree).  Host pointers unless a parameter is named *_dev.
+ *
+ * Threading: calls on different indexes are independent; searches on one index
+ * are serialised by the caller (they share the index's workspace); add / free
+ * must not overlap a search on the same index.
+ */
+#ifndef RAG_HIP_H
+#define RAG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAG_ABI_VERSION 1
+
+enum rag_status {
+    RAG_OK = 0,
+    RAG_ERR_INVALID = 1,      /* bad argument (message says which) */
+    RAG_ERR_HIP = 2,          /* a HIP runtime call failed */
+    RAG_ERR_OOM = 3,          /* device allocation failed */
+    RAG_ERR_UNSUPPORTED = 4   /* valid request this build does not cover */
+};
+
+/* vector_db/search_optimizer.py:33-36 MetricType.  COSINE rows are normalised
+ * when added and queries when searched (what a Qdrant COSINE collection does),
+ * after which the scan is an inner product. */
+enum rag_metric { RAG_METRIC_IP = 0, RAG_METRIC_COSINE = 1 };
+
+/* FLAT = exhaustive scan (FAISS IndexFlatIP semantics); IVF = coarse lists
+ * (FAISS IndexIVFFlat semantics with an inner-product flat quantiser). */
+enum rag_kind { RAG_KIND_FLAT = 0, RAG_KIND_IVF = 1 };
+
+/* similarity used by MMR, vector_db/mmr_diversifier.py:257-268 */
+enum rag_mmr_metric { RAG_MMR_COSINE = 0, RAG_MMR_DOT = 1, RAG_MMR_EUCLIDEAN = 2 };
+
+typedef struct rag_index rag_index_t;
+
+/* ---- library ------------------------------------------------------------ */
+int rag_version(void);
+/* thread-local message of the last failing call on this thread */
+const char* rag_last_error(void);
+int rag_device_count(int* count);
+
+/* ---- index lifetime ------------------------------------------------------
+ * One rag_index_t replaces one Qdrant collection + its QdrantSearchOptimizer
+ * (vector_db/search_optimizer.py:68-86, created at
+ * vector_db/storage_manager.py:190-221).  Rows live in HBM on `device`. */
+int rag_index_create(int dim, int metric, int kind, int device, rag_index_t** out);
+/* vector_db/storage_manager.py:718-750 delete_index / :985-993 cleanup */
+int rag_index_free(rag_index_t* h);
+/* capacity hint so that a known-size corpus is allocated once */
+int rag_index_reserve(rag_index_t* h, int64_t nrows);
+/* vector_db/storage_manager.py:254-366 add_vectors -> qdrant upsert
+ * (vector_db/qdrant_client.py:207-246).  x is row-major n x dim fp32.  ids == NULL
+ * gives each row the id "id_base + row position" (FAISS insertion order). */
+int rag_index_add(rag_index_t* h, int64_t n, const float* x, const int64_t* ids);
+/* same, rows already in device memory of the index's device (copied) */
+int rag_index_add_device(rag_index_t* h, int64_t n, const float* x_dev, const int64_t* ids);
+/* zero-copy: search directly in the caller's device buffer (row-major n x dim,
+ * dim % 4 == 0, 16-byte aligned, kept alive by the caller; COSINE rows are
+ * normalised in place).  Only on an empty index. */
+int rag_index_adopt_device(rag_index_t* h, int64_t n, float* x_dev);
+/* ids reported for rows without explicit ids start here (row shard of a
+ * multi-GPU corpus: base = first global row of the shard) */
+int rag_index_set_id_base(rag_index_t* h, int64_t base);
+int64_t rag_index_ntotal(const rag_index_t* h);
+int rag_index_dim(const rag_index_t* h);
+/* vector_db/qdrant_client.py:826-883 soft delete (payload is_active) and
+ * restore: rows[i] are row positions; active = 0 hides them from every search. */
+int rag_index_set_active(rag_index_t* h, int64_t n, const int64_t* rows, int active);
+/* vector_db/storage_manager.py:558-602 get_vector_by_chunk_id ->
+ * qdrant retrieve(with_vectors): copy rows (by row position) to out[n x dim]. */
+int rag_index_reconstruct(rag_index_t* h, int64_t n, const int64_t* rows, float* out);
+
+/* ---- search ---------------------------------------------------------------
+ * vector_db/search_optimizer.py:146-274 search (nq = 1) and :276-323
+ * batch_search (nq > 1), i.e. the client.search call at :213-222.
+ *   q         nq x dim fp32
+ *   k         hits per query (limit)
+ *   min_score keep hits with score >= min_score (score_threshold); pass
+ *             -FLT_MAX for none
+ *   nprobe    IVF lists to scan (ignored by FLAT)
+ *   row_mask  NULL or ntotal bytes, 1 = row may be returned (payload filters
+ *             resolved by the caller, search_optimizer.py:173-201)
+ *   D, I      nq x k, best first; ties broken by lower row position; unfilled
+ *             slots I = -1, D = -FLT_MAX. */
+int rag_index_search(rag_index_t* h, int64_t nq, const float* q, int k, float min_score,
+                     int nprobe, const uint8_t* row_mask, float* D, int64_t* I);
+/* same with every buffer in device memory; enqueued on `stream` (a hipStream_t,
+ * NULL = default stream) and not synchronised. */
+int rag_index_search_device(rag_index_t* h, int64_t nq, const float* q_dev, int k,
+                            float min_score, int nprobe, const uint8_t* row_mask_dev,
+                            float* D_dev, int64_t* I_dev, void* stream);
+/* which kernel the last search on this index used ("scan", "gemm", "ivf") */
+const char* rag_index_last_path(const rag_index_t* h);
+
+/* multi-GPU step after the all-gather of per-shard results: merge `nlists`
+ * result sets laid out [nlists][nq][k] into the k best per query (same order
+ * rule, ids are final ids here).  Device buffers, enqueued on `stream`. */
+int rag_merge_topk_device(int nlists, int64_t nq, int k, const float* D_dev,
+                          const int64_t* I_dev, float* D_out_dev, int64_t* I_out_dev,
+                          int device, void* stream);
+
+/* ---- IVF ------------------------------------------------------------------
+ * FAISS IndexIVFFlat: centroids given (nlist x dim) or, with centroids == NULL,
+ * taken as the first nlist rows of `sample`; later adds go to the list of the
+ * centroid with the largest inner product. */
+int rag_index_train_ivf(rag_index_t* h, int nlist, const float* centroids,
+                        int64_t nsample, const float* sample);
+
+/* ---- score fusion (device kernels over the candidate set) -------------------
+ * vector_db/storage_manager.py:653-709 contextual_search fusion.
+ * Candidates 0..n-1 in dict insertion order; a[i] / b[i] the content / context
+ * score (0.0 where a side is missing).  out_score[i] = a*wa + b*wb; kept when
+ * !use_threshold or score >= threshold; order[] = kept candidates by score
+ * descending, stable, first k.  Returns the count through n_out. */
+int rag_fuse_weighted(int64_t n, const double* a, const double* b, double wa, double wb,
+                      int use_threshold, double threshold, int k,
+                      int32_t* order, double* out_score, int32_t* n_out);
+/* vector_db/search_manager.py:1041-1075 hybrid fusion: a / b = semantic / BM25
+ * score per candidate, has_a / has_b presence flags, max_a / max_b the divisors
+ * (the caller computes them over the full lists, 1.0 for an empty list).
+ * A zero divisor is reported as RAG_ERR_INVALID (the reference's
+ * ZeroDivisionError path, :1098-1101, is the caller's to take). */
+int rag_fuse_maxnorm(int64_t n, const double* a, const double* b, const uint8_t* has_a,
+                     const uint8_t* has_b, double max_a, double max_b, double wa, double wb,
+                     int k, int32_t* order, double* out_score, double* out_a, double* out_b,
+                     int32_t* n_out);
+
+/* vector_db/mmr_diversifier.py:216-289 _mmr_greedy_selection.
+ *   emb       n x d, fp32 (emb_is_f64 = 0) or fp64 (1); arithmetic is fp64
+ *   rel       n normalised relevance scores (mmr_diversifier.py:188-200)
+ *   out_idx   max_results selected candidate positions in selection order */
+int rag_mmr_select(int64_t n, int d, const void* emb, int emb_is_f64, const double* rel,
+                   double lambda, double similarity_threshold, int metric, int max_results,
+                   int device, int32_t* out_idx, int32_t* n_out);
+/* same, embeddings taken from rows of an index (no host copy of vectors) */
+int rag_mmr_select_rows(rag_index_t* h, int64_t n, const int64_t* rows, const double* rel,
+                        double lambda, double similarity_threshold, int metric,
+                        int max_results, int32_t* out_idx, int32_t* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAG_HIP_H */

@@ -1,0 +1,492 @@
+// C ABI of librag_hip.so: index lifetime, ingest, search dispatch, result merge.
+// The declarations (and the reference interfaces they stand in for) are in
+// include/rag_hip.h.
+#include <float.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "index.h"
+#include "topk_keys.h"
+
+namespace rag {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+int Workspace::ensure(size_t need) {
+    if (need <= bytes) return RAG_OK;
+    size_t want = std::max(need, bytes + bytes / 2);
+    want = (want + 255) & ~(size_t)255;
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) return fail(RAG_ERR_OOM, "workspace hipMalloc(" + std::to_string(want) + "): " + hipGetErrorString(e));
+    if (ptr) (void)hipFree(ptr);
+    ptr = p;
+    bytes = want;
+    return RAG_OK;
+}
+void Workspace::release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+__global__ void fill_results_kernel(float* D, long long* I, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        D[i] = -FLT_MAX;
+        I[i] = -1;
+    }
+}
+__global__ void and_masks_kernel(const uint8_t* a, const uint8_t* b, long long n, uint8_t* out) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = (a[i] != 0 && b[i] != 0) ? 1 : 0;
+}
+__global__ void scatter_bytes_kernel(uint8_t* dst, const long long* rows, long long n, long long limit, uint8_t v) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = rows[i];
+        if (r >= 0 && r < limit) dst[r] = v;
+    }
+}
+__global__ void iota_ids_kernel(long long* ids, long long begin, long long end, long long base) {
+    for (long long i = begin + blockIdx.x * (long long)blockDim.x + threadIdx.x; i < end; i += (long long)gridDim.x * blockDim.x)
+        ids[i] = base + i;
+}
+
+static int grid_for(long long n, int block = 256, int maxb = 4096) {
+    long long b = (n + block - 1) / block;
+    if (b < 1) b = 1;
+    if (b > maxb) b = maxb;
+    return (int)b;
+}
+
+// make room for `extra` more rows (and their ids / active bytes)
+static int ensure_rows(rag_index* h, long long extra) {
+    const long long need = h->n + extra;
+    if (need <= h->cap) return RAG_OK;
+    if (h->adopted) return fail(RAG_ERR_INVALID, "index uses an adopted device buffer and cannot grow");
+    long long ncap = std::max(need, h->reserve_hint);
+    if (h->cap > 0 && ncap < h->cap + h->cap / 2 && need > h->reserve_hint) ncap = h->cap + h->cap / 2;
+    float* nx = nullptr;
+    RAG_HIP_CHECK(hipMalloc((void**)&nx, (size_t)ncap * h->ld * sizeof(float)));
+    if (h->n > 0) RAG_HIP_CHECK(hipMemcpy(nx, h->X, (size_t)h->n * h->ld * sizeof(float), hipMemcpyDeviceToDevice));
+    if (h->X) (void)hipFree(h->X);
+    h->X = nx;
+    if (h->ids_dev) {
+        long long* ni = nullptr;
+        RAG_HIP_CHECK(hipMalloc((void**)&ni, (size_t)ncap * sizeof(long long)));
+        if (h->n > 0) RAG_HIP_CHECK(hipMemcpy(ni, h->ids_dev, (size_t)h->n * sizeof(long long), hipMemcpyDeviceToDevice));
+        (void)hipFree(h->ids_dev);
+        h->ids_dev = ni;
+    }
+    if (h->active) {
+        uint8_t* na = nullptr;
+        RAG_HIP_CHECK(hipMalloc((void**)&na, (size_t)ncap));
+        RAG_HIP_CHECK(hipMemset(na, 1, (size_t)ncap));
+        if (h->n > 0) RAG_HIP_CHECK(hipMemcpy(na, h->active, (size_t)h->n, hipMemcpyDeviceToDevice));
+        (void)hipFree(h->active);
+        h->active = na;
+    }
+    h->cap = ncap;
+    return RAG_OK;
+}
+
+// record ids for rows [n, n+count) (ids may be nullptr)
+static int append_ids(rag_index* h, long long count, const int64_t* ids) {
+    if (!ids && !h->ids_dev) return RAG_OK;
+    if (!h->ids_dev) {
+        RAG_HIP_CHECK(hipMalloc((void**)&h->ids_dev, (size_t)h->cap * sizeof(long long)));
+        if (h->n > 0) {
+            hipLaunchKernelGGL(iota_ids_kernel, dim3(grid_for(h->n)), dim3(256), 0, h->stream, h->ids_dev, 0LL, h->n, h->id_base);
+            RAG_HIP_CHECK(hipGetLastError());
+        }
+    }
+    if (ids) {
+        RAG_HIP_CHECK(hipMemcpyAsync(h->ids_dev + h->n, ids, (size_t)count * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+    } else {
+        hipLaunchKernelGGL(iota_ids_kernel, dim3(grid_for(count)), dim3(256), 0, h->stream, h->ids_dev, h->n, h->n + count, h->id_base);
+        RAG_HIP_CHECK(hipGetLastError());
+    }
+    RAG_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return RAG_OK;
+}
+
+int ivf_assign_new_rows(rag_index* h, long long first, long long count);   // ivf.hip
+int ivf_search_device(rag_index* h, long long nq, const float* qbuf, int k, float min_score, int nprobe,
+                      const uint8_t* mask, float* D, long long* I, hipStream_t s);
+void ivf_free(rag_index* h);
+int gemm_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask,
+                     float* D, long long* I, hipStream_t s);                 // gemm_topk.hip
+bool gemm_topk_supported(const rag_index* h, long long nq, int k);
+
+// blocks for the scan: enough waves to fill the chip, not more lists than rows justify
+static int scan_blocks(const rag_index* h) {
+    const int tile = scan_rows_per_tile(h->ld / 4);
+    const long long ntiles = (h->n + tile - 1) / tile;
+    // at least ~64 tiles per wave before adding another wave; at most 4 blocks per CU
+    long long waves = (ntiles + 63) / 64;
+    long long blocks = (waves + 3) / 4;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 1024) blocks = 1024;
+    return (int)blocks;
+}
+
+static int flat_scan_search(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask,
+                            float* D, long long* I, hipStream_t s) {
+    const int blocks = scan_blocks(h);
+    const int waves = blocks * 4;
+    const int group_max = (k > 64) ? 1 : 8;
+    // workspace: partial keys for one group of queries (after the padded queries)
+    const size_t qbytes = ((size_t)nq * h->ld * sizeof(float) + 255) & ~(size_t)255;
+    const size_t pbytes = (size_t)group_max * waves * k * sizeof(u64);
+    // (the caller placed qbuf at ws.ptr; keep it there)
+    if (int rc = h->ws.ensure(qbytes + pbytes)) return rc;
+    u64* part = reinterpret_cast<u64*>(static_cast<char*>(h->ws.ptr) + qbytes);
+    int cap = std::max(2048, 2 * pow2_ceil(k));
+    long long q0 = 0;
+    while (q0 < nq) {
+        int g = 1;
+        if (k <= 64) {
+            const long long left = nq - q0;
+            g = left >= 8 ? 8 : left >= 4 ? 4 : left >= 2 ? 2 : 1;
+        }
+        ScanArgs a;
+        a.X = h->X;
+        a.Q = qbuf + q0 * h->ld;
+        a.mask = mask;
+        a.part = part;
+        a.n = h->n;
+        a.d4 = h->ld / 4;
+        a.nch = 0;
+        a.k = k;
+        a.capw = 0;
+        RAG_HIP_CHECK(launch_flat_scan(a, g, blocks, s));
+        MergeArgs m;
+        m.keys = part;
+        m.per_query = (long long)waves * k;
+        m.k = k;
+        m.cap = cap;
+        m.min_score = min_score;
+        m.row_ids = h->ids_dev;
+        m.id_base = h->id_base;
+        m.slot_ids = nullptr;
+        m.slot_stride = 0;
+        m.D = D + q0 * k;
+        m.I = I + q0 * k;
+        RAG_HIP_CHECK(launch_merge_keys(m, g, s));
+        q0 += g;
+    }
+    h->last_path = "scan";
+    return RAG_OK;
+}
+
+}  // namespace rag
+
+using namespace rag;
+
+extern "C" {
+
+int rag_version(void) { return RAG_ABI_VERSION; }
+const char* rag_last_error(void) { return g_err.c_str(); }
+
+int rag_device_count(int* count) {
+    if (!count) return fail(RAG_ERR_INVALID, "count is NULL");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(RAG_ERR_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    *count = c;
+    return RAG_OK;
+}
+
+int rag_index_create(int dim, int metric, int kind, int device, rag_index_t** out) {
+    if (!out) return fail(RAG_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (dim < 1 || dim > 65536) return fail(RAG_ERR_INVALID, "dim must be in [1, 65536]");
+    if (metric != RAG_METRIC_IP && metric != RAG_METRIC_COSINE) return fail(RAG_ERR_INVALID, "unknown metric");
+    if (kind != RAG_KIND_FLAT && kind != RAG_KIND_IVF) return fail(RAG_ERR_INVALID, "unknown index kind");
+    int ndev = 0;
+    RAG_HIP_CHECK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(RAG_ERR_INVALID, "device " + std::to_string(device) + " out of range (" + std::to_string(ndev) + " visible)");
+    DeviceGuard g(device);
+    if (!g.ok) return fail(RAG_ERR_HIP, "hipSetDevice failed");
+    rag_index* h = new rag_index();
+    h->dim = dim;
+    h->ld = (dim + 3) & ~3;
+    h->metric = metric;
+    h->kind = kind;
+    h->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete h;
+        return fail(RAG_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    *out = h;
+    return RAG_OK;
+}
+
+int rag_index_free(rag_index_t* h) {
+    if (!h) return RAG_OK;
+    DeviceGuard g(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->X && !h->adopted) (void)hipFree(h->X);
+    if (h->ids_dev) (void)hipFree(h->ids_dev);
+    if (h->active) (void)hipFree(h->active);
+    ivf_free(h);
+    h->ws.release();
+    h->ws2.release();
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return RAG_OK;
+}
+
+int rag_index_reserve(rag_index_t* h, int64_t nrows) {
+    if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
+    if (nrows < 0) return fail(RAG_ERR_INVALID, "nrows < 0");
+    DeviceGuard g(h->device);
+    h->reserve_hint = nrows;
+    if (nrows > h->cap && !h->adopted) return ensure_rows(h, nrows - h->n);
+    return RAG_OK;
+}
+
+static int add_common(rag_index_t* h, int64_t n, const float* x, bool x_on_device, const int64_t* ids) {
+    if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
+    if (n < 0) return fail(RAG_ERR_INVALID, "n < 0");
+    if (n == 0) return RAG_OK;
+    if (!x) return fail(RAG_ERR_INVALID, "x is NULL");
+    if (h->n + n > 0x7FFFFFF0LL) return fail(RAG_ERR_UNSUPPORTED, "more than 2^31 rows per index");
+    if (h->kind == RAG_KIND_IVF && h->ivf.nlist == 0) return fail(RAG_ERR_INVALID, "IVF index must be trained before rows are added");
+    DeviceGuard g(h->device);
+    if (int rc = ensure_rows(h, n)) return rc;
+    const int normalize = h->metric == RAG_METRIC_COSINE;
+    float* dst = h->X + (size_t)h->n * h->ld;
+    if (x_on_device) {
+        if (!normalize && h->ld == h->dim) {
+            RAG_HIP_CHECK(hipMemcpyAsync(dst, x, (size_t)n * h->dim * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        } else {
+            RAG_HIP_CHECK(launch_ingest_rows(x, n, h->dim, h->ld, normalize, dst, h->stream));
+        }
+    } else if (!normalize && h->ld == h->dim) {
+        RAG_HIP_CHECK(hipMemcpyAsync(dst, x, (size_t)n * h->dim * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    } else {
+        // stage host rows through the workspace in chunks, then pad / normalise on device
+        const long long chunk_rows = std::max<long long>(1, (64LL << 20) / ((long long)h->dim * 4));
+        for (long long r0 = 0; r0 < n; r0 += chunk_rows) {
+            const long long c = std::min<long long>(chunk_rows, n - r0);
+            if (int rc = h->ws.ensure((size_t)c * h->dim * sizeof(float))) return rc;
+            RAG_HIP_CHECK(hipMemcpyAsync(h->ws.ptr, x + (size_t)r0 * h->dim, (size_t)c * h->dim * sizeof(float), hipMemcpyHostToDevice, h->stream));
+            RAG_HIP_CHECK(launch_ingest_rows(static_cast<const float*>(h->ws.ptr), c, h->dim, h->ld, normalize, dst + (size_t)r0 * h->ld, h->stream));
+            RAG_HIP_CHECK(hipStreamSynchronize(h->stream));
+        }
+    }
+    RAG_HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (int rc = append_ids(h, n, ids)) return rc;
+    const long long first = h->n;
+    h->n += n;
+    if (h->kind == RAG_KIND_IVF) return ivf_assign_new_rows(h, first, n);
+    return RAG_OK;
+}
+
+int rag_index_add(rag_index_t* h, int64_t n, const float* x, const int64_t* ids) { return add_common(h, n, x, false, ids); }
+int rag_index_add_device(rag_index_t* h, int64_t n, const float* x_dev, const int64_t* ids) { return add_common(h, n, x_dev, true, ids); }
+
+int rag_index_adopt_device(rag_index_t* h, int64_t n, float* x_dev) {
+    if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
+    if (h->n != 0 || h->X) return fail(RAG_ERR_INVALID, "adopt needs an empty index");
+    if (h->kind != RAG_KIND_FLAT) return fail(RAG_ERR_UNSUPPORTED, "adopt is for FLAT indexes");
+    if (n < 0 || (n > 0 && !x_dev)) return fail(RAG_ERR_INVALID, "bad buffer");
+    if (h->dim % 4 != 0) return fail(RAG_ERR_INVALID, "adopt needs dim % 4 == 0");
+    if ((reinterpret_cast<uintptr_t>(x_dev) & 15) != 0) return fail(RAG_ERR_INVALID, "adopt needs a 16-byte aligned buffer");
+    if (n > 0x7FFFFFF0LL) return fail(RAG_ERR_UNSUPPORTED, "more than 2^31 rows per index");
+    DeviceGuard g(h->device);
+    if (h->metric == RAG_METRIC_COSINE && n > 0) {
+        RAG_HIP_CHECK(launch_ingest_rows(x_dev, n, h->dim, h->ld, 1, x_dev, h->stream));
+        RAG_HIP_CHECK(hipStreamSynchronize(h->stream));
+    }
+    h->X = x_dev;
+    h->n = n;
+    h->cap = n;
+    h->adopted = true;
+    return RAG_OK;
+}
+
+int rag_index_set_id_base(rag_index_t* h, int64_t base) {
+    if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
+    h->id_base = base;
+    return RAG_OK;
+}
+
+int64_t rag_index_ntotal(const rag_index_t* h) { return h ? h->n : 0; }
+int rag_index_dim(const rag_index_t* h) { return h ? h->dim : 0; }
+const char* rag_index_last_path(const rag_index_t* h) { return h ? h->last_path : "none"; }
+
+int rag_index_set_active(rag_index_t* h, int64_t n, const int64_t* rows, int active) {
+    if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
+    if (n < 0 || (n > 0 && !rows)) return fail(RAG_ERR_INVALID, "bad rows");
+    if (n == 0) return RAG_OK;
+    for (int64_t i = 0; i < n; ++i)
+        if (rows[i] < 0 || rows[i] >= h->n) return fail(RAG_ERR_INVALID, "row " + std::to_string(rows[i]) + " out of range");
+    DeviceGuard g(h->device);
+    if (!h->active) {
+        if (active) return RAG_OK;   // everything is active already
+        RAG_HIP_CHECK(hipMalloc((void**)&h->active, (size_t)std::max<long long>(h->cap, 1)));
+        RAG_HIP_CHECK(hipMemset(h->active, 1, (size_t)std::max<long long>(h->cap, 1)));
+    }
+    if (int rc = h->ws2.ensure((size_t)n * sizeof(long long))) return rc;
+    RAG_HIP_CHECK(hipMemcpyAsync(h->ws2.ptr, rows, (size_t)n * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(scatter_bytes_kernel, dim3(grid_for(n)), dim3(256), 0, h->stream, h->active,
+                       static_cast<const long long*>(h->ws2.ptr), (long long)n, h->n, (uint8_t)(active ? 1 : 0));
+    RAG_HIP_CHECK(hipGetLastError());
+    RAG_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return RAG_OK;
+}
+
+int rag_index_reconstruct(rag_index_t* h, int64_t n, const int64_t* rows, float* out) {
+    if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
+    if (n < 0 || (n > 0 && (!rows || !out))) return fail(RAG_ERR_INVALID, "bad arguments");
+    if (n == 0) return RAG_OK;
+    for (int64_t i = 0; i < n; ++i)
+        if (rows[i] < 0 || rows[i] >= h->n) return fail(RAG_ERR_INVALID, "row " + std::to_string(rows[i]) + " out of range");
+    DeviceGuard g(h->device);
+    const size_t rbytes = ((size_t)n * sizeof(long long) + 255) & ~(size_t)255;
+    if (int rc = h->ws2.ensure(rbytes + (size_t)n * h->dim * sizeof(float))) return rc;
+    long long* drows = static_cast<long long*>(h->ws2.ptr);
+    float* dout = reinterpret_cast<float*>(static_cast<char*>(h->ws2.ptr) + rbytes);
+    RAG_HIP_CHECK(hipMemcpyAsync(drows, rows, (size_t)n * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+    RAG_HIP_CHECK(launch_gather_rows(h->X, h->dim, h->ld, n, drows, h->n, dout, h->stream));
+    RAG_HIP_CHECK(hipMemcpyAsync(out, dout, (size_t)n * h->dim * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    RAG_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return RAG_OK;
+}
+
+int rag_index_search_device(rag_index_t* h, int64_t nq, const float* q_dev, int k, float min_score, int nprobe,
+                            const uint8_t* row_mask_dev, float* D_dev, int64_t* I_dev, void* stream) {
+    if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
+    if (nq < 0) return fail(RAG_ERR_INVALID, "nq < 0");
+    if (k < 1 || k > 1024) return fail(RAG_ERR_INVALID, "k must be in [1, 1024]");
+    if (nq == 0) return RAG_OK;
+    if (!q_dev || !D_dev || !I_dev) return fail(RAG_ERR_INVALID, "NULL buffer");
+    if (min_score != min_score) return fail(RAG_ERR_INVALID, "min_score is NaN");
+    DeviceGuard g(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    long long* I = reinterpret_cast<long long*>(I_dev);
+    if (h->n == 0) {
+        hipLaunchKernelGGL(fill_results_kernel, dim3(grid_for(nq * k)), dim3(256), 0, s, D_dev, I, (long long)nq * k);
+        RAG_HIP_CHECK(hipGetLastError());
+        h->last_path = "empty";
+        return RAG_OK;
+    }
+    // effective row mask = soft-delete mask AND caller's filter mask
+    const uint8_t* mask = row_mask_dev;
+    if (h->active) {
+        if (row_mask_dev) {
+            if (int rc = h->ws2.ensure((size_t)h->n)) return rc;
+            hipLaunchKernelGGL(and_masks_kernel, dim3(grid_for(h->n)), dim3(256), 0, s, h->active, row_mask_dev, h->n,
+                               static_cast<uint8_t*>(h->ws2.ptr));
+            RAG_HIP_CHECK(hipGetLastError());
+            mask = static_cast<const uint8_t*>(h->ws2.ptr);
+        } else {
+            mask = h->active;
+        }
+    }
+    // padded (and for COSINE normalised) queries at the start of the workspace
+    const size_t qbytes = ((size_t)nq * h->ld * sizeof(float) + 255) & ~(size_t)255;
+    if (int rc = h->ws.ensure(qbytes)) return rc;
+    RAG_HIP_CHECK(launch_prep_queries(q_dev, nq, h->dim, h->ld, h->metric == RAG_METRIC_COSINE, static_cast<float*>(h->ws.ptr), s));
+    if (h->kind == RAG_KIND_IVF) {
+        return ivf_search_device(h, nq, static_cast<const float*>(h->ws.ptr), k, min_score, nprobe, mask, D_dev, I, s);
+    }
+    if (gemm_topk_supported(h, nq, k)) {
+        return gemm_topk_search(h, nq, static_cast<const float*>(h->ws.ptr), k, min_score, mask, D_dev, I, s);
+    }
+    // ws.ensure inside flat_scan_search may move the workspace: grow it first, then re-prep if it moved
+    {
+        const int blocks = scan_blocks(h);
+        const size_t pbytes = (size_t)((k > 64) ? 1 : 8) * blocks * 4 * k * sizeof(u64);
+        void* before = h->ws.ptr;
+        if (int rc = h->ws.ensure(qbytes + pbytes)) return rc;
+        if (h->ws.ptr != before)
+            RAG_HIP_CHECK(launch_prep_queries(q_dev, nq, h->dim, h->ld, h->metric == RAG_METRIC_COSINE, static_cast<float*>(h->ws.ptr), s));
+    }
+    return flat_scan_search(h, nq, static_cast<const float*>(h->ws.ptr), k, min_score, mask, D_dev, I, s);
+}
+
+int rag_index_search(rag_index_t* h, int64_t nq, const float* q, int k, float min_score, int nprobe,
+                     const uint8_t* row_mask, float* D, int64_t* I) {
+    if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
+    if (nq < 0) return fail(RAG_ERR_INVALID, "nq < 0");
+    if (k < 1 || k > 1024) return fail(RAG_ERR_INVALID, "k must be in [1, 1024]");
+    if (nq == 0) return RAG_OK;
+    if (!q || !D || !I) return fail(RAG_ERR_INVALID, "NULL buffer");
+    DeviceGuard g(h->device);
+    // staging in a separate allocation from the search workspaces
+    static thread_local Workspace stage[64];
+    Workspace& st = stage[h->device & 63];
+    const size_t qb = ((size_t)nq * h->dim * sizeof(float) + 255) & ~(size_t)255;
+    const size_t db = ((size_t)nq * k * sizeof(float) + 255) & ~(size_t)255;
+    const size_t ib = ((size_t)nq * k * sizeof(long long) + 255) & ~(size_t)255;
+    const size_t mb = row_mask ? (((size_t)h->n + 255) & ~(size_t)255) : 0;
+    if (int rc = st.ensure(qb + db + ib + mb)) return rc;
+    char* base = static_cast<char*>(st.ptr);
+    float* q_dev = reinterpret_cast<float*>(base);
+    float* D_dev = reinterpret_cast<float*>(base + qb);
+    int64_t* I_dev = reinterpret_cast<int64_t*>(base + qb + db);
+    uint8_t* m_dev = row_mask ? reinterpret_cast<uint8_t*>(base + qb + db + ib) : nullptr;
+    RAG_HIP_CHECK(hipMemcpyAsync(q_dev, q, (size_t)nq * h->dim * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (row_mask && h->n > 0) RAG_HIP_CHECK(hipMemcpyAsync(m_dev, row_mask, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+    if (int rc = rag_index_search_device(h, nq, q_dev, k, min_score, nprobe, m_dev, D_dev, I_dev, h->stream)) return rc;
+    RAG_HIP_CHECK(hipMemcpyAsync(D, D_dev, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    RAG_HIP_CHECK(hipMemcpyAsync(I, I_dev, (size_t)nq * k * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+    RAG_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return RAG_OK;
+}
+
+int rag_merge_topk_device(int nlists, int64_t nq, int k, const float* D_dev, const int64_t* I_dev, float* D_out_dev,
+                          int64_t* I_out_dev, int device, void* stream) {
+    if (nlists < 1 || nq < 0 || k < 1 || k > 1024) return fail(RAG_ERR_INVALID, "bad nlists / nq / k");
+    if (nq == 0) return RAG_OK;
+    if (!D_dev || !I_dev || !D_out_dev || !I_out_dev) return fail(RAG_ERR_INVALID, "NULL buffer");
+    if ((long long)nlists * k > 0x7FFFFFFFLL) return fail(RAG_ERR_INVALID, "nlists * k too large");
+    DeviceGuard g(device);
+    if (!g.ok) return fail(RAG_ERR_HIP, "hipSetDevice failed");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    static thread_local Workspace keyws[64];
+    Workspace& ws = keyws[device & 63];
+    if (int rc = ws.ensure((size_t)nq * nlists * k * sizeof(u64))) return rc;
+    u64* keys = static_cast<u64*>(ws.ptr);
+    RAG_HIP_CHECK(launch_lists_to_keys(nlists, nq, k, D_dev, reinterpret_cast<const long long*>(I_dev), keys, s));
+    MergeArgs m;
+    m.keys = keys;
+    m.per_query = (long long)nlists * k;
+    m.k = k;
+    m.cap = std::max(2048, 2 * pow2_ceil(k));
+    m.min_score = -FLT_MAX;
+    m.row_ids = nullptr;
+    m.id_base = 0;
+    m.slot_ids = reinterpret_cast<const long long*>(I_dev);   // [nlists][nq][k]
+    m.slot_stride = nq;
+    m.D = D_out_dev;
+    m.I = reinterpret_cast<long long*>(I_out_dev);
+    RAG_HIP_CHECK(launch_merge_keys(m, nq, s));
+    return RAG_OK;
+}
+
+}  // extern "C"

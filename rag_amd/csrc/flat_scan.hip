@@ -1,0 +1,439 @@
+// Exhaustive inner-product scan for one query or a handful of queries, fused with
+// top-k selection (gfx950).
+//
+// Roofline: HBM.  Every corpus row is read exactly once per launch with 16-byte
+// per-lane loads (one wave instruction = 1 KiB, or 2 x 512 B, contiguous);
+// arithmetic is ~1/30 of the VALU budget at batch 1, so the kernel's job is to
+// keep enough loads in flight and never touch a row twice.  Algorithmic bytes
+// per row = 4*ld (+1 with a row mask).
+//
+// Selection: each wave keeps its own candidate list and never synchronises with
+// other waves inside the scan loop.
+//   k <= 64  : a sorted list of 64 keys, one per lane (DPP shift insert).
+//   k <= 1024: a wave-private LDS buffer of 2*pow2(k) keys, bitonic-sorted and cut
+//              to k whenever it fills.
+// A row is a candidate only if its key beats the wave's current k-th key, which
+// after warm-up is rare.  Every wave writes its k keys to `part`; a second, tiny
+// kernel (merge_keys_kernel) merges the P lists per query in LDS.
+#include "topk_keys.h"
+#include "kernels.h"
+
+namespace rag {
+
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+    if constexpr (LPR == 64) return wave_sum_to_lane63(v);
+    else if constexpr (LPR == 32) return half_sum_to_lane31(v);
+    else return row16_sum(v);
+}
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float dot4(const f4& a, const f4& b, float acc) {
+    acc = fmaf(a[0], b[0], acc);
+    acc = fmaf(a[1], b[1], acc);
+    acc = fmaf(a[2], b[2], acc);
+    acc = fmaf(a[3], b[3], acc);
+    return acc;
+}
+__device__ __forceinline__ f4 f4_zero() { return (f4){0.f, 0.f, 0.f, 0.f}; }
+
+// LPR  lanes that share one row (64 / 32 / 16); RPS = 64/LPR rows per wave step
+// CH   float4 chunks per lane per row, compile time (0: run-time count a.nch)
+// U    wave steps per tile (rows in flight per wave = U*RPS)
+// NQ   queries scored against every row (1: query fragment in registers; >1: LDS)
+// BIGK false: register list (k <= 64); true: LDS buffer (NQ must be 1)
+template <int LPR, int CH, int U, int NQ, bool BIGK>
+__global__ __launch_bounds__(256) void flat_scan_kernel(ScanArgs a) {
+    constexpr int RPS = 64 / LPR;
+    constexpr int TILE = RPS * U;
+    static_assert(!BIGK || NQ == 1, "LDS-buffer selection handles one query per launch");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    const int sub = lane / LPR;
+    const int l = lane % LPR;
+    const int nwaves = gridDim.x * 4;
+    const int w = blockIdx.x * 4 + wib;
+    const int d4 = a.d4;
+    const int nch = CH ? CH : a.nch;
+    const f4* __restrict__ X4 = reinterpret_cast<const f4*>(a.X);
+    const f4* __restrict__ Q4 = reinterpret_cast<const f4*>(a.Q);
+
+    // ---- query fragments --------------------------------------------------
+    constexpr int QREG = (NQ == 1 && CH > 0) ? CH : 1;
+    f4 qf[QREG];
+    f4* qlds = reinterpret_cast<f4*>(smem);          // [NQ][d4] when not in registers
+    constexpr bool Q_IN_REGS = (NQ == 1 && CH > 0);
+    if constexpr (Q_IN_REGS) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int col = c * LPR + l;
+            qf[c] = (col < d4) ? Q4[col] : f4_zero();
+        }
+    } else {
+        for (int i = threadIdx.x; i < NQ * d4; i += 256) qlds[i] = Q4[i];
+        __syncthreads();
+    }
+    // wave-private LDS candidate buffer (BIGK), placed after the query image
+    u64* wbuf = nullptr;
+    int capw = 0;
+    if constexpr (BIGK) {
+        capw = a.capw;
+        const size_t qbytes = Q_IN_REGS ? 0 : (((size_t)NQ * d4 * 16 + 15) & ~(size_t)15);
+        wbuf = reinterpret_cast<u64*>(smem + qbytes) + (size_t)wib * capw;
+    }
+
+    // ---- selection state ----------------------------------------------------
+    u64 list[NQ];
+    u64 thr[NQ];
+    float thr_f[NQ];
+    int cnt = 0;   // BIGK: keys in wbuf
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) { list[qi] = KEY_EMPTY; thr[qi] = KEY_EMPTY; thr_f[qi] = -INFINITY; }
+    const int k = a.k;
+
+    const long long ntiles = (a.n + TILE - 1) / TILE;
+    for (long long tile = w; tile < ntiles; tile += nwaves) {
+        const long long row0 = tile * TILE;
+        float acc[U][NQ];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi) acc[u][qi] = 0.f;
+
+        // rows of the tile that exist and are not masked out: bit j = row0 + j
+        bool rv = false;
+        if (lane < TILE) {
+            const long long r = row0 + lane;
+            rv = r < a.n;
+            if (rv && a.mask) rv = a.mask[r] != 0;
+        }
+        const u64 rowvalid = __ballot(rv);
+
+        if constexpr (CH > 0) {
+            f4 x[U][CH];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                long long r = row0 + u * RPS + sub;
+                r = r < a.n ? r : a.n - 1;
+                const f4* xr = X4 + r * (long long)d4;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const int col = c * LPR + l;
+                    x[u][c] = (col < d4) ? xr[col] : f4_zero();
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if constexpr (Q_IN_REGS) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) acc[u][0] = dot4(x[u][c], qf[c], acc[u][0]);
+                } else {
+                    const int col = c * LPR + l;
+#pragma unroll
+                    for (int qi = 0; qi < NQ; ++qi) {
+                        const f4 qv = (col < d4) ? qlds[qi * d4 + col] : f4_zero();
+#pragma unroll
+                        for (int u = 0; u < U; ++u) acc[u][qi] = dot4(x[u][c], qv, acc[u][qi]);
+                    }
+                }
+            }
+        } else {
+            for (int c = 0; c < nch; ++c) {
+                const int col = c * LPR + l;
+                const bool in = col < d4;
+                f4 x[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    long long r = row0 + u * RPS + sub;
+                    r = r < a.n ? r : a.n - 1;
+                    x[u] = in ? X4[r * (long long)d4 + col] : f4_zero();
+                }
+#pragma unroll
+                for (int qi = 0; qi < NQ; ++qi) {
+                    const f4 qv = in ? qlds[qi * d4 + col] : f4_zero();
+#pragma unroll
+                    for (int u = 0; u < U; ++u) acc[u][qi] = dot4(x[u], qv, acc[u][qi]);
+                }
+            }
+        }
+
+        // ---- reduce over the lanes of a row; result sits in the group's last lane
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi) acc[u][qi] = group_sum<LPR>(acc[u][qi]);
+
+        // ---- candidate test + insert (wave-uniform control flow) ---------------
+        const bool result_lane = (l == LPR - 1);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const u64 uvalid = (rowvalid >> (u * RPS)) & ((RPS == 64) ? ~0ull : ((1ull << RPS) - 1));
+            // expand "row s of this step is valid" to the result lane of group s
+            const bool lane_ok = result_lane && ((uvalid >> sub) & 1ull);
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi) {
+                u64 m = __ballot(lane_ok && acc[u][qi] >= thr_f[qi]);
+                while (m) {
+                    const int j = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc[u][qi]), j));
+                    const uint32_t row = (uint32_t)(row0 + u * RPS + j / LPR);
+                    const u64 key = make_key(sc, row);
+                    if (key > thr[qi]) {
+                        if constexpr (!BIGK) {
+                            wave_list_insert(list[qi], key, lane);
+                            thr[qi] = readlane_u64(list[qi], k - 1);
+                        } else {
+                            if (lane == 0) wbuf[cnt] = key;
+                            ++cnt;
+                            if (cnt == capw) {
+                                bitonic_sort_desc_lds(wbuf, capw, lane, 64, SyncWave());
+                                cnt = k;
+                                thr[qi] = wbuf[k - 1];
+                            }
+                        }
+                        thr_f[qi] = (thr[qi] == KEY_EMPTY) ? -INFINITY : key_score(thr[qi]);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- publish this wave's k keys per query -----------------------------------
+    if constexpr (!BIGK) {
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi)
+            if (lane < k) a.part[((size_t)qi * nwaves + w) * k + lane] = list[qi];
+    } else {
+        // pad with empties, sort, write the first k
+        for (int i = cnt + lane; i < capw; i += 64) wbuf[i] = KEY_EMPTY;
+        bitonic_sort_desc_lds(wbuf, capw, lane, 64, SyncWave());
+        for (int i = lane; i < k; i += 64) a.part[(size_t)w * k + i] = wbuf[i];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Merge P key lists of length k per query into the final k hits (one workgroup
+// per query).  Keys stream through an LDS buffer: a key is appended only if it
+// beats the current k-th key; the buffer is bitonic-sorted and cut to k when it
+// cannot take another 1024 keys.
+__global__ __launch_bounds__(1024) void merge_keys_kernel(MergeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* buf = reinterpret_cast<u64*>(smem);
+    const int tid = threadIdx.x;
+    const int cap = a.cap;
+    const int k = a.k;
+    u64* s_thr = buf + cap;                               // [cap]   current k-th key
+    int* s_cnt = reinterpret_cast<int*>(buf + cap + 1);   // [cap+1] keys in buf
+    const long long q = blockIdx.x;
+    const u64* in = a.keys + (size_t)q * a.per_query;
+    for (int i = tid; i < cap; i += 1024) buf[i] = KEY_EMPTY;
+    if (tid == 0) { *s_cnt = 0; *s_thr = KEY_EMPTY; }
+    __syncthreads();
+    for (long long base = 0; base < a.per_query; base += 1024) {
+        const int c = *s_cnt;
+        __syncthreads();              // every thread has read the count before anyone appends
+        if (c + 1024 > cap) {
+            bitonic_sort_desc_lds(buf, cap, tid, 1024, SyncBlock());
+            const u64 t = buf[k - 1];
+            __syncthreads();
+            for (int i = k + tid; i < cap; i += 1024) buf[i] = KEY_EMPTY;
+            if (tid == 0) { *s_cnt = k; *s_thr = t; }
+            __syncthreads();
+        }
+        const u64 thr = *s_thr;
+        const long long i = base + tid;
+        const u64 key = (i < a.per_query) ? in[i] : KEY_EMPTY;
+        if (key > thr) {
+            const int pos = atomicAdd(s_cnt, 1);
+            buf[pos] = key;
+        }
+        __syncthreads();
+    }
+    bitonic_sort_desc_lds(buf, cap, tid, 1024, SyncBlock());
+    // ---- finalise: keys -> (score, id), threshold, padding ------------------------
+    for (int j = tid; j < k; j += 1024) {
+        const u64 key = buf[j];
+        float s = -3.402823466e+38f;
+        long long id = -1;
+        if (key != KEY_EMPTY) {
+            const float sc = key_score(key);
+            if (sc >= a.min_score) {
+                const uint32_t slot = key_row(key);
+                s = sc;
+                if (a.slot_ids) {   // merge of finished lists [nlists][nq][k]: slot = list*k + rank
+                    const uint32_t g = slot / (uint32_t)k, j = slot % (uint32_t)k;
+                    id = a.slot_ids[((size_t)g * a.slot_stride + q) * k + j];
+                }
+                else if (a.row_ids) id = a.row_ids[slot];
+                else id = a.id_base + (long long)slot;
+            }
+        }
+        a.D[(size_t)q * k + j] = s;
+        a.I[(size_t)q * k + j] = id;
+    }
+}
+
+// (D, I) result lists -> keys whose "row" is the slot in the gathered list
+// [nlists][nq][k] -> keys [nq][nlists*k]; an unfilled slot (I < 0) gives no key.
+__global__ void lists_to_keys_kernel(int nlists, long long nq, int k, const float* D, const long long* I, u64* keys) {
+    const long long total = (long long)nlists * nq * k;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(t % k);
+        const long long q = (t / k) % nq;
+        const int g = (int)(t / ((long long)k * nq));
+        const uint32_t slot = (uint32_t)(g * k + j);
+        keys[(size_t)q * nlists * k + slot] = (I[t] < 0) ? KEY_EMPTY : make_key(D[t], slot);
+    }
+}
+
+// queries -> padded (ld) and, for COSINE, normalised copies
+__global__ void prep_queries_kernel(const float* q, int d, int ld, int normalize, float* out) {
+    const long long qi = blockIdx.x;
+    const float* src = q + qi * d;
+    float* dst = out + qi * ld;
+    __shared__ float s_part[4];
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < d; i += blockDim.x) { const float v = src[i]; ss += v * v; }
+    ss = wave_sum_to_lane63(ss);
+    if ((threadIdx.x & 63) == 63) s_part[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    float tot = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) tot += s_part[i];
+    float inv = 1.f;
+    if (normalize) { const float nrm = sqrtf(tot); inv = nrm > 0.f ? 1.f / nrm : 1.f; }
+    for (int i = threadIdx.x; i < ld; i += blockDim.x) dst[i] = (i < d) ? src[i] * inv : 0.f;
+}
+
+// rows: copy n x d -> n x ld (zero padded), optionally normalised (one wave per row)
+__global__ void ingest_rows_kernel(const float* src, long long n, int d, int ld, int normalize, float* dst) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
+    const long long nw = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long r = wave; r < n; r += nw) {
+        const float* s = src + r * d;
+        float ss = 0.f;
+        for (int i = lane; i < d; i += 64) { const float v = s[i]; ss += v * v; }
+        float inv = 1.f;
+        if (normalize) {
+            ss = wave_sum_to_lane63(ss);
+            const float tot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ss), 63));
+            const float nrm = sqrtf(tot);
+            inv = nrm > 0.f ? 1.f / nrm : 1.f;
+        }
+        float* o = dst + r * ld;
+        for (int i = lane; i < ld; i += 64) o[i] = (i < d) ? s[i] * inv : 0.f;
+    }
+}
+
+__global__ void gather_rows_kernel(const float* X, int d, int ld, long long n, const long long* rows, long long ntotal, float* out) {
+    const long long r = blockIdx.x;
+    if (r >= n) return;
+    const long long src = rows[r];
+    for (int i = threadIdx.x; i < d; i += blockDim.x)
+        out[r * d + i] = (src >= 0 && src < ntotal) ? X[src * ld + i] : 0.f;
+}
+
+// ---------------------------------------------------------------------------
+// host-side launchers
+template <int LPR, int CH, int U, int NQ, bool BIGK>
+static hipError_t launch_scan_t(const ScanArgs& a, int blocks, size_t lds, hipStream_t s) {
+    auto kern = flat_scan_kernel<LPR, CH, U, NQ, BIGK>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int NQ, bool BIGK>
+static hipError_t launch_scan_nq(const ScanArgs& a, int blocks, size_t lds, hipStream_t s) {
+    const int d4 = a.d4;
+    // compile-time chunk counts for the common embedding widths
+    if (d4 == 192) return launch_scan_t<64, 3, 4, NQ, BIGK>(a, blocks, lds, s);          // d = 768
+    if (d4 == 256) return launch_scan_t<64, 4, 2, NQ, BIGK>(a, blocks, lds, s);          // d = 1024
+    if (d4 == 96) return launch_scan_t<32, 3, 4, NQ, BIGK>(a, blocks, lds, s);           // d = 384
+    if (d4 == 128) return launch_scan_t<64, 2, 4, NQ, BIGK>(a, blocks, lds, s);          // d = 512
+    if (d4 == 64) return launch_scan_t<64, 1, 4, NQ, BIGK>(a, blocks, lds, s);           // d = 256
+    if (d4 == 32) return launch_scan_t<32, 1, 4, NQ, BIGK>(a, blocks, lds, s);           // d = 128
+    if (d4 <= 16) return launch_scan_t<16, 1, 4, NQ, BIGK>(a, blocks, lds, s);           // d <= 64
+    if (d4 <= 32) return launch_scan_t<32, 0, 4, NQ, BIGK>(a, blocks, lds, s);
+    return launch_scan_t<64, 0, 4, NQ, BIGK>(a, blocks, lds, s);
+}
+
+int scan_rows_per_tile(int d4) {
+    if (d4 == 256) return 2;
+    if (d4 == 96 || d4 == 32) return 8;
+    if (d4 <= 16) return 16;
+    if (d4 < 32) return 8;
+    return 4;
+}
+int scan_lanes_per_row(int d4) {
+    if (d4 == 96 || d4 == 32) return 32;
+    if (d4 <= 16) return 16;
+    if (d4 < 32) return 32;
+    return 64;
+}
+
+hipError_t launch_flat_scan(ScanArgs a, int nq, int blocks, hipStream_t s) {
+    const bool bigk = a.k > 64;
+    const int lpr = scan_lanes_per_row(a.d4);
+    a.nch = (a.d4 + lpr - 1) / lpr;
+    // queries live in registers only for NQ == 1 with a compile-time chunk count
+    const bool q_in_regs = (nq == 1) && (a.d4 == 192 || a.d4 == 256 || a.d4 == 96 || a.d4 == 128 || a.d4 == 64 || a.d4 == 32 || a.d4 <= 16);
+    size_t lds = q_in_regs ? 0 : (((size_t)nq * a.d4 * 16 + 15) & ~(size_t)15);
+    if (bigk) {
+        a.capw = 2 * pow2_ceil(a.k);
+        lds += (size_t)4 * a.capw * sizeof(u64);
+        return launch_scan_nq<1, true>(a, blocks, lds, s);
+    }
+    switch (nq) {
+        case 1: return launch_scan_nq<1, false>(a, blocks, lds, s);
+        case 2: return launch_scan_nq<2, false>(a, blocks, lds, s);
+        case 4: return launch_scan_nq<4, false>(a, blocks, lds, s);
+        case 8: return launch_scan_nq<8, false>(a, blocks, lds, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_merge_keys(const MergeArgs& a, long long nq, hipStream_t s) {
+    const size_t lds = (size_t)(a.cap + 2) * sizeof(u64);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(merge_keys_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(merge_keys_kernel, dim3((unsigned)nq), dim3(1024), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_lists_to_keys(int nlists, long long nq, int k, const float* D, const long long* I, u64* keys, hipStream_t s) {
+    const long long total = (long long)nlists * nq * k;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(lists_to_keys_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, nlists, nq, k, D, I, keys);
+    return hipGetLastError();
+}
+
+hipError_t launch_prep_queries(const float* q, long long nq, int d, int ld, int normalize, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(prep_queries_kernel, dim3((unsigned)nq), dim3(256), 0, s, q, d, ld, normalize, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_ingest_rows(const float* src, long long n, int d, int ld, int normalize, float* dst, hipStream_t s) {
+    long long blocks = (n + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(ingest_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, n, d, ld, normalize, dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_rows(const float* X, int d, int ld, long long n, const long long* rows, long long ntotal, float* out, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)n), dim3(256), 0, s, X, d, ld, n, rows, ntotal, out);
+    return hipGetLastError();
+}
+
+}  // namespace rag

@@ -1,0 +1,66 @@
+// The index object behind rag_index_t and the error plumbing of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/rag_hip.h"
+#include "kernels.h"
+
+namespace rag {
+
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define RAG_HIP_CHECK(expr)                                                                  \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return ::rag::fail(_e == hipErrorOutOfMemory ? RAG_ERR_OOM : RAG_ERR_HIP,        \
+                               std::string(#expr) + ": " + hipGetErrorString(_e));           \
+    } while (0)
+
+// Grow-only device scratch owned by an index (or by the library per device).
+struct Workspace {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need);   // returns rag_status
+    void release();
+};
+
+struct IvfState {
+    int nlist = 0;
+    float* centroids = nullptr;          // [nlist][ld] device
+    std::vector<long long> list_begin;   // host copy of CSR offsets, nlist + 1
+    long long* list_begin_dev = nullptr;
+    // rows are stored grouped by list: X / row_ids of the index are in list order
+    bool built = false;
+    // rows added since the last build, kept until build() packs them
+    std::vector<int> pending_assign;
+};
+
+}  // namespace rag
+
+struct rag_index {
+    int dim = 0;
+    int ld = 0;          // row stride in floats, multiple of 4
+    int metric = 0;
+    int kind = 0;
+    int device = 0;
+    float* X = nullptr;
+    long long n = 0;
+    long long cap = 0;
+    bool adopted = false;
+    long long* ids_dev = nullptr;   // explicit ids (cap entries) or nullptr
+    long long id_base = 0;
+    uint8_t* active = nullptr;      // nullptr = every row active
+    long long n_inactive = 0;
+    long long reserve_hint = 0;
+    rag::Workspace ws;              // queries, partial keys, staging
+    rag::Workspace ws2;             // combined masks, host-API result staging
+    hipStream_t stream = nullptr;   // used by the host-pointer entry points
+    const char* last_path = "none";
+    rag::IvfState ivf;
+};

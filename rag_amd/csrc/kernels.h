@@ -1,0 +1,46 @@
+// Kernel argument blocks and host-side launchers shared by the translation units
+// of librag_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rag {
+
+typedef unsigned long long u64;
+
+struct ScanArgs {
+    const float* X;        // corpus rows, row stride ld = 4*d4 floats, 16-byte aligned
+    const float* Q;        // nq padded queries, stride ld
+    const uint8_t* mask;   // nullptr or n bytes, 1 = row may be returned
+    u64* part;             // [nq][waves][k] per-wave candidate keys
+    long long n;           // rows
+    int d4;                // float4 per row
+    int nch;               // chunks per lane per row (run-time variant)
+    int k;
+    int capw;              // k > 64: keys per wave-private LDS buffer
+};
+
+struct MergeArgs {
+    const u64* keys;             // [nq][per_query]
+    long long per_query;
+    int k;
+    int cap;                     // LDS buffer capacity (power of two, >= 2k, >= 2048)
+    float min_score;
+    const long long* row_ids;    // nullptr: id = id_base + row
+    long long id_base;
+    const long long* slot_ids;   // merge of finished lists [nlists][nq][k]: slot = list*k + rank
+    long long slot_stride;       //   = nq
+    float* D;                    // [nq][k]
+    long long* I;                // [nq][k]
+};
+
+int scan_rows_per_tile(int d4);
+int scan_lanes_per_row(int d4);
+hipError_t launch_flat_scan(ScanArgs a, int nq, int blocks, hipStream_t s);
+hipError_t launch_merge_keys(const MergeArgs& a, long long nq, hipStream_t s);
+hipError_t launch_lists_to_keys(int nlists, long long nq, int k, const float* D, const long long* I, u64* keys, hipStream_t s);
+hipError_t launch_prep_queries(const float* q, long long nq, int d, int ld, int normalize, float* out, hipStream_t s);
+hipError_t launch_ingest_rows(const float* src, long long n, int d, int ld, int normalize, float* dst, hipStream_t s);
+hipError_t launch_gather_rows(const float* X, int d, int ld, long long n, const long long* rows, long long ntotal, float* out, hipStream_t s);
+
+}  // namespace rag

@@ -1,0 +1,17 @@
+// Entry points whose kernels are not built yet answer RAG_ERR_UNSUPPORTED.
+#include "index.h"
+namespace rag {
+int ivf_assign_new_rows(rag_index*, long long, long long) { return fail(RAG_ERR_UNSUPPORTED, "IVF not built"); }
+int ivf_search_device(rag_index*, long long, const float*, int, float, int, const uint8_t*, float*, long long*, hipStream_t) { return fail(RAG_ERR_UNSUPPORTED, "IVF not built"); }
+void ivf_free(rag_index*) {}
+int gemm_topk_search(rag_index*, long long, const float*, int, float, const uint8_t*, float*, long long*, hipStream_t) { return fail(RAG_ERR_UNSUPPORTED, "gemm path not built"); }
+bool gemm_topk_supported(const rag_index*, long long, int) { return false; }
+}
+using namespace rag;
+extern "C" {
+int rag_index_train_ivf(rag_index_t*, int, const float*, int64_t, const float*) { return fail(RAG_ERR_UNSUPPORTED, "IVF not built"); }
+int rag_fuse_weighted(int64_t, const double*, const double*, double, double, int, double, int, int32_t*, double*, int32_t*) { return fail(RAG_ERR_UNSUPPORTED, "fusion not built"); }
+int rag_fuse_maxnorm(int64_t, const double*, const double*, const uint8_t*, const uint8_t*, double, double, double, double, int, int32_t*, double*, double*, double*, int32_t*) { return fail(RAG_ERR_UNSUPPORTED, "fusion not built"); }
+int rag_mmr_select(int64_t, int, const void*, int, const double*, double, double, int, int, int, int32_t*, int32_t*) { return fail(RAG_ERR_UNSUPPORTED, "mmr not built"); }
+int rag_mmr_select_rows(rag_index_t*, int64_t, const int64_t*, const double*, double, double, int, int, int32_t*, int32_t*) { return fail(RAG_ERR_UNSUPPORTED, "mmr not built"); }
+}

@@ -1,0 +1,201 @@
+"""Device-resident vector index: a thin object over the rag_index_t handle.
+
+One ``DeviceIndex`` stands where the reference keeps one Qdrant collection plus
+its ``QdrantSearchOptimizer`` (vector_db/search_optimizer.py:68-86).  Host
+arrays (numpy) go through the host-pointer entry points; ``torch`` tensors that
+live on the index's GPU go through the ``*_device`` entry points on torch's
+current stream without leaving HBM.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
+
+FLT_MAX = float(np.finfo(np.float32).max)
+MAX_K = 1024
+
+
+def _is_torch_cuda(x) -> bool:
+    return type(x).__module__.startswith("torch") and hasattr(x, "is_cuda") and x.is_cuda
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class DeviceIndex:
+    """metric: 'ip' | 'cosine'; kind: 'flat' | 'ivf'."""
+
+    def __init__(self, dim: int, metric: str = "cosine", kind: str = "flat", device: int = 0):
+        metrics = {"ip": _lib.METRIC_IP, "dot": _lib.METRIC_IP, "cosine": _lib.METRIC_COSINE}
+        kinds = {"flat": _lib.KIND_FLAT, "ivf": _lib.KIND_IVF}
+        if metric not in metrics:
+            raise ValueError(f"unknown metric {metric!r}")
+        if kind not in kinds:
+            raise ValueError(f"unknown index kind {kind!r}")
+        self.dim = int(dim)
+        self.metric = metric
+        self.kind = kind
+        self.device = int(device)
+        self._h = C.c_void_p()
+        self._keepalive = None
+        check(lib.rag_index_create(self.dim, metrics[metric], kinds[kind], self.device, C.byref(self._h)))
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib.rag_index_free(self._h)
+            self._h = C.c_void_p()
+            self._keepalive = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self) -> int:
+        return int(lib.rag_index_ntotal(self._h))
+
+    @property
+    def ntotal(self) -> int:
+        return len(self)
+
+    @property
+    def last_path(self) -> str:
+        return (lib.rag_index_last_path(self._h) or b"").decode()
+
+    # -------------------------------------------------------------------- ingest
+    def reserve(self, nrows: int) -> None:
+        check(lib.rag_index_reserve(self._h, int(nrows)))
+
+    def set_id_base(self, base: int) -> None:
+        check(lib.rag_index_set_id_base(self._h, int(base)))
+
+    def add(self, x, ids=None) -> None:
+        ids_np = None if ids is None else np.ascontiguousarray(ids, dtype=np.int64)
+        if _is_torch_cuda(x):
+            import torch
+            if x.dtype != torch.float32 or x.dim() != 2 or x.shape[1] != self.dim:
+                raise ValueError(f"expected float32 [n, {self.dim}] tensor")
+            if x.device.index != self.device:
+                raise ValueError("tensor is on another device than the index")
+            x = x.contiguous()
+            torch.cuda.current_stream(x.device).synchronize()
+            n = x.shape[0]
+            if ids_np is not None and ids_np.shape != (n,):
+                raise ValueError("ids must have one entry per row")
+            check(lib.rag_index_add_device(self._h, n, C.c_void_p(x.data_ptr()), _ptr(ids_np)))
+            return
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.ndim != 2 or x.shape[1] != self.dim:
+            raise ValueError(f"expected float32 [n, {self.dim}] array, got {x.shape}")
+        if ids_np is not None and ids_np.shape != (x.shape[0],):
+            raise ValueError("ids must have one entry per row")
+        check(lib.rag_index_add(self._h, x.shape[0], _ptr(x), _ptr(ids_np)))
+
+    def adopt(self, x) -> None:
+        """Search in place in a torch CUDA tensor [n, dim] fp32 (no copy; the index
+        keeps a reference).  COSINE indexes normalise the rows in place."""
+        import torch
+        if not _is_torch_cuda(x) or x.dtype != torch.float32 or x.dim() != 2 or x.shape[1] != self.dim:
+            raise ValueError(f"expected a CUDA float32 [n, {self.dim}] tensor")
+        if not x.is_contiguous():
+            raise ValueError("tensor must be contiguous")
+        if x.device.index != self.device:
+            raise ValueError("tensor is on another device than the index")
+        torch.cuda.current_stream(x.device).synchronize()
+        check(lib.rag_index_adopt_device(self._h, x.shape[0], C.c_void_p(x.data_ptr())))
+        self._keepalive = x
+
+    def set_active(self, rows, active: bool) -> None:
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        check(lib.rag_index_set_active(self._h, rows.size, _ptr(rows), 1 if active else 0))
+
+    def reconstruct(self, rows) -> np.ndarray:
+        rows = np.ascontiguousarray(rows, dtype=np.int64).reshape(-1)
+        out = np.empty((rows.size, self.dim), dtype=np.float32)
+        check(lib.rag_index_reconstruct(self._h, rows.size, _ptr(rows), _ptr(out)))
+        return out
+
+    def train_ivf(self, nlist: int, centroids=None, sample=None) -> None:
+        c = None if centroids is None else np.ascontiguousarray(centroids, dtype=np.float32)
+        s = None if sample is None else np.ascontiguousarray(sample, dtype=np.float32)
+        if c is not None and c.shape != (nlist, self.dim):
+            raise ValueError("centroids must be [nlist, dim]")
+        ns = 0 if s is None else s.shape[0]
+        check(lib.rag_index_train_ivf(self._h, int(nlist), _ptr(c), ns, _ptr(s)))
+
+    # -------------------------------------------------------------------- search
+    def search(self, q, k: int, min_score: Optional[float] = None, nprobe: int = 1,
+               row_mask=None) -> Tuple[object, object]:
+        """Returns (D [nq,k] float32, I [nq,k] int64), numpy for numpy queries and
+        CUDA tensors for CUDA-tensor queries."""
+        k = int(k)
+        if not 1 <= k <= MAX_K:
+            raise ValueError(f"k must be in [1, {MAX_K}]")
+        ms = -FLT_MAX if min_score is None else float(min_score)
+        if _is_torch_cuda(q):
+            import torch
+            if q.dim() == 1:
+                q = q[None, :]
+            if q.dtype != torch.float32 or q.shape[1] != self.dim:
+                raise ValueError(f"expected float32 [nq, {self.dim}] tensor")
+            if q.device.index != self.device:
+                raise ValueError("tensor is on another device than the index")
+            q = q.contiguous()
+            nq = q.shape[0]
+            D = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+            I = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+            m_ptr = None
+            if row_mask is not None:
+                if not _is_torch_cuda(row_mask) or row_mask.dtype != torch.uint8 or row_mask.numel() != len(self):
+                    raise ValueError("row_mask must be a CUDA uint8 tensor with one byte per row")
+                row_mask = row_mask.contiguous()
+                m_ptr = C.c_void_p(row_mask.data_ptr())
+            stream = torch.cuda.current_stream(q.device).cuda_stream
+            check(lib.rag_index_search_device(self._h, nq, C.c_void_p(q.data_ptr()), k, ms, int(nprobe), m_ptr,
+                                              C.c_void_p(D.data_ptr()), C.c_void_p(I.data_ptr()),
+                                              C.c_void_p(stream)))
+            return D, I
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        if q.ndim != 2 or q.shape[1] != self.dim:
+            raise ValueError(f"expected float32 [nq, {self.dim}] array, got {q.shape}")
+        nq = q.shape[0]
+        D = np.empty((nq, k), dtype=np.float32)
+        I = np.empty((nq, k), dtype=np.int64)
+        m = None
+        if row_mask is not None:
+            m = np.ascontiguousarray(row_mask, dtype=np.uint8).reshape(-1)
+            if m.size != len(self):
+                raise ValueError("row_mask must have one byte per row")
+        check(lib.rag_index_search(self._h, nq, _ptr(q), k, ms, int(nprobe), _ptr(m), _ptr(D), _ptr(I)))
+        return D, I
+
+
+def merge_topk(D, I, device: Optional[int] = None):
+    """Merge result sets stacked as [nlists, nq, k] CUDA tensors into [nq, k]
+    (the step after the all-gather of per-shard results)."""
+    import torch
+    if not (_is_torch_cuda(D) and _is_torch_cuda(I)) or D.dim() != 3 or D.shape != I.shape:
+        raise ValueError("expected CUDA tensors D, I of shape [nlists, nq, k]")
+    if D.dtype != torch.float32 or I.dtype != torch.int64:
+        raise ValueError("expected float32 scores and int64 ids")
+    D = D.contiguous()
+    I = I.contiguous()
+    nl, nq, k = D.shape
+    dev = D.device.index if device is None else device
+    Do = torch.empty((nq, k), dtype=torch.float32, device=D.device)
+    Io = torch.empty((nq, k), dtype=torch.int64, device=D.device)
+    stream = torch.cuda.current_stream(D.device).cuda_stream
+    check(lib.rag_merge_topk_device(nl, nq, k, C.c_void_p(D.data_ptr()), C.c_void_p(I.data_ptr()),
+                                    C.c_void_p(Do.data_ptr()), C.c_void_p(Io.data_ptr()), dev,
+                                    C.c_void_p(stream)))
+    return Do, Io

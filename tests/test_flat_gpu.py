@@ -1,0 +1,221 @@
+"""Parity of the HIP exhaustive search (through the C ABI) with the CPU oracle.
+
+Tolerance (stated by the target): ids equal except where scores tie within the
+tolerance; scores within 1e-5 relative (+1e-6 absolute for scores near zero)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-5, 1e-6
+
+
+def _unit(rng, n, d):
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return x
+
+
+def _check(D, I, X, Q, k, **kw):
+    from oracle import flat
+    Dr, Ir = flat.flat_ip_search(X, Q, k, **kw)
+    bad = flat.compare_topk(D, I, Dr, Ir, rtol=RTOL, atol=ATOL)
+    assert bad == [], bad[:5]
+
+
+@pytest.mark.parametrize("n,d", [(100_000, 384), (50_000, 768), (20_000, 1024), (30_000, 512),
+                                 (10_000, 256), (9_999, 128), (5_000, 100), (3_000, 10), (777, 64),
+                                 (4_321, 1536), (2_000, 36)])
+def test_flat_ip_matches_oracle(n, d):
+    from rag_amd import DeviceIndex
+    rng = np.random.default_rng(n + d)
+    X = _unit(rng, n, d)
+    Q = _unit(rng, 13, d)
+    idx = DeviceIndex(d, metric="ip")
+    idx.add(X[: n // 2])
+    idx.add(X[n // 2:])
+    assert len(idx) == n
+    for nq in (1, 2, 3, 8, 13):
+        D, I = idx.search(Q[:nq], 10)
+        assert D.dtype == np.float32 and I.dtype == np.int64 and D.shape == (nq, 10)
+        _check(D, I, X, Q[:nq], 10)
+    assert idx.last_path == "scan"
+    idx.close()
+
+
+@pytest.mark.parametrize("k", [1, 2, 10, 33, 64, 65, 100, 200, 400, 1024])
+def test_k_range(k):
+    from rag_amd import DeviceIndex
+    rng = np.random.default_rng(k)
+    n, d = 60_000, 384
+    X = _unit(rng, n, d)
+    Q = _unit(rng, 3, d)
+    idx = DeviceIndex(d, metric="ip")
+    idx.add(X)
+    D, I = idx.search(Q, k)
+    _check(D, I, X, Q, k)
+    idx.close()
+
+
+def test_small_and_empty():
+    from rag_amd import DeviceIndex
+    rng = np.random.default_rng(3)
+    d = 48
+    idx = DeviceIndex(d, metric="ip")
+    q = _unit(rng, 2, d)
+    D, I = idx.search(q, 5)
+    assert np.all(I == -1) and np.all(D == -np.finfo(np.float32).max)
+    X = _unit(rng, 3, d)
+    idx.add(X)
+    D, I = idx.search(q, 5)                      # k > n: padded
+    _check(D, I, X, q, 5)
+    assert np.all(I[:, 3:] == -1)
+    D, I = idx.search(q, 100)                    # k > 64 and > n
+    _check(D, I, X, q, 100)
+    idx.close()
+
+
+def test_ties_lower_id_first_and_health_check_vectors():
+    from rag_amd import DeviceIndex
+    # vector_db/health_checker.py:228-249: two parallel vectors, both cosine 1.0
+    idx = DeviceIndex(384, metric="cosine")
+    idx.add(np.array([[0.1] * 384, [0.2] * 384], dtype=np.float32))
+    D, I = idx.search(np.array([0.15] * 384, dtype=np.float32), 2)
+    assert I.tolist() == [[0, 1]]
+    assert np.allclose(D, 1.0, atol=1e-6)
+    idx.close()
+    rng = np.random.default_rng(9)
+    base = _unit(rng, 50, 768)
+    X = np.tile(base, (40, 1))                   # every row repeated 40 times
+    idx = DeviceIndex(768, metric="ip")
+    idx.add(X)
+    D, I = idx.search(base[7], 40)
+    assert I[0].tolist() == [7 + 50 * j for j in range(40)]
+    assert np.all(D[0] == D[0, 0])
+    D, I = idx.search(base[7], 100)
+    assert I[0, :40].tolist() == [7 + 50 * j for j in range(40)]
+    idx.close()
+
+
+def test_mask_min_score_ids_and_soft_delete():
+    from rag_amd import DeviceIndex
+    rng = np.random.default_rng(11)
+    n, d = 40_000, 768
+    X = _unit(rng, n, d)
+    Q = _unit(rng, 4, d)
+    ids = rng.permutation(10 * n)[:n].astype(np.int64) + (1 << 40)
+    idx = DeviceIndex(d, metric="ip")
+    idx.add(X, ids=ids)
+    D, I = idx.search(Q, 10)
+    _check(D, I, X, Q, 10, ids=ids)
+    mask = (rng.uniform(size=n) < 0.3).astype(np.uint8)
+    D, I = idx.search(Q, 10, row_mask=mask)
+    _check(D, I, X, Q, 10, ids=ids, row_mask=mask)
+    D0, I0 = idx.search(Q[:1], 10)
+    thr = float(D0[0, 4]) - 1e-7
+    D, I = idx.search(Q[:1], 10, min_score=thr)
+    assert (I[0] >= 0).sum() == 5 and np.array_equal(I[0, :5], I0[0, :5])
+    assert np.all(D[0, 5:] == -np.finfo(np.float32).max)
+    # soft delete (vector_db/qdrant_client.py:826-883) then restore
+    from oracle import flat
+    _, Ipos = flat.flat_ip_search(X, Q[:1], 3)
+    idx.set_active(Ipos[0], False)
+    m2 = np.ones(n, dtype=np.uint8)
+    m2[Ipos[0]] = 0
+    D, I = idx.search(Q, 10)
+    _check(D, I, X, Q, 10, ids=ids, row_mask=m2)
+    D, I = idx.search(Q, 10, row_mask=mask)
+    _check(D, I, X, Q, 10, ids=ids, row_mask=mask & m2)
+    idx.set_active(Ipos[0], True)
+    D, I = idx.search(Q, 10)
+    _check(D, I, X, Q, 10, ids=ids)
+    idx.close()
+
+
+def test_cosine_metric_normalises_rows_and_queries():
+    from oracle import flat
+    from rag_amd import DeviceIndex
+    rng = np.random.default_rng(13)
+    n, d = 20_000, 384
+    X = (rng.standard_normal((n, d)) * rng.uniform(0.1, 5.0, (n, 1))).astype(np.float32)
+    X[17] = 0.0
+    Q = (rng.standard_normal((5, d)) * 3.0).astype(np.float32)
+    idx = DeviceIndex(d, metric="cosine")
+    idx.add(X)
+    D, I = idx.search(Q, 10)
+    Xn, Qn = flat.l2_normalize_rows(X), flat.l2_normalize_rows(Q)
+    _check(D, I, Xn, Qn, 10)
+    # reconstruct returns the stored (normalised) rows
+    R = idx.reconstruct([0, 17, n - 1])
+    assert np.allclose(R, Xn[[0, 17, n - 1]], atol=1e-6)
+    # and agrees with the reference's brute-force cosine scan on a small slice
+    ref = flat.embedded_cosine_scan(X[:300], Q[0], 5)
+    small = DeviceIndex(d, metric="cosine")
+    small.add(X[:300])
+    Ds, Is = small.search(Q[0], 5)
+    assert Is[0].tolist() == [i for i, _ in ref]
+    assert np.allclose(Ds[0], [s for _, s in ref], rtol=RTOL, atol=ATOL)
+    idx.close()
+    small.close()
+
+
+def test_torch_device_path_and_adopt():
+    import torch
+    from rag_amd import DeviceIndex
+    rng = np.random.default_rng(17)
+    n, d = 30_000, 768
+    X = _unit(rng, n, d)
+    Q = _unit(rng, 6, d)
+    xt = torch.from_numpy(X).cuda()
+    qt = torch.from_numpy(Q).cuda()
+    idx = DeviceIndex(d, metric="ip")
+    idx.adopt(xt)
+    D, I = idx.search(qt, 10)
+    assert D.is_cuda and I.is_cuda
+    torch.cuda.synchronize()
+    _check(D.cpu().numpy(), I.cpu().numpy(), X, Q, 10)
+    m = torch.from_numpy((rng.uniform(size=n) < 0.5).astype(np.uint8)).cuda()
+    D, I = idx.search(qt, 10, row_mask=m)
+    _check(D.cpu().numpy(), I.cpu().numpy(), X, Q, 10, row_mask=m.cpu().numpy())
+    idx.close()
+    idx2 = DeviceIndex(d, metric="ip")
+    idx2.set_id_base(1_000_000)
+    idx2.add(xt)
+    D, I = idx2.search(qt[:1], 5)
+    _check(D.cpu().numpy(), I.cpu().numpy() - 1_000_000, X, Q[:1], 5)
+    idx2.close()
+
+
+def test_merge_topk_device():
+    import torch
+    from rag_amd import DeviceIndex, merge_topk
+    rng = np.random.default_rng(19)
+    n, d, G = 32_000, 384, 4
+    X = _unit(rng, n, d)
+    Q = _unit(rng, 9, d)
+    parts = []
+    for g in range(G):
+        sh = DeviceIndex(d, metric="ip")
+        lo, hi = g * n // G, (g + 1) * n // G
+        sh.set_id_base(lo)
+        sh.add(X[lo:hi])
+        parts.append(sh.search(torch.from_numpy(Q).cuda(), 10))
+        sh.close()
+    D = torch.stack([p[0] for p in parts])
+    I = torch.stack([p[1] for p in parts])
+    Dm, Im = merge_topk(D, I)
+    _check(Dm.cpu().numpy(), Im.cpu().numpy(), X, Q, 10)
+
+
+def test_errors_are_reported():
+    from rag_amd import DeviceIndex, RagHipError
+    idx = DeviceIndex(16, metric="ip")
+    with pytest.raises(ValueError):
+        idx.search(np.zeros((1, 16), np.float32), 5000)
+    with pytest.raises(ValueError):
+        idx.add(np.zeros((3, 8), np.float32))
+    with pytest.raises(RagHipError):
+        idx.reconstruct([5])
+    with pytest.raises(RagHipError):
+        DeviceIndex(16, device=99)
+    idx.close()
