@@ -104,11 +104,20 @@ int rag_index_search_device(rag_index_t* h, int64_t nq, const float* q_dev, int 
 const char* rag_index_last_path(const rag_index_t* h);
 
 /* multi-GPU step after the all-gather of per-shard results: merge `nlists`
- * result sets laid out [nlists][nq][k] into the k best per query (same order
- * rule, ids are final ids here).  Device buffers, enqueued on `stream`. */
-int rag_merge_topk_device(int nlists, int64_t nq, int k, const float* D_dev,
-                          const int64_t* I_dev, float* D_out_dev, int64_t* I_out_dev,
-                          int device, void* stream);
+ * result sets, list g at D_dev + g*d_list_stride / I_dev + g*i_list_stride
+ * (strides in elements; 0 = dense nq*k), each [nq][k], into the k best per
+ * query (same order rule; ids are final ids here; ties between lists go to the
+ * lower list).  Device buffers, enqueued on `stream`. */
+int rag_merge_topk_device(int nlists, int64_t nq, int k, const float* D_dev, int64_t d_list_stride,
+                          const int64_t* I_dev, int64_t i_list_stride, float* D_out_dev,
+                          int64_t* I_out_dev, int device, void* stream);
+
+/* measurement: while enabled, every search records a HIP event pair around its
+ * dominant kernel (the corpus scan / GEMM) on the search's stream.  read
+ * synchronises those events and returns the summed kernel time and the number
+ * of launches since the last reset. */
+int rag_index_profile_enable(rag_index_t* h, int enable);
+int rag_index_profile_read(rag_index_t* h, double* kernel_ms, int64_t* launches, int reset);
 
 /* ---- IVF ------------------------------------------------------------------
  * FAISS IndexIVFFlat: centroids given (nlist x dim) or, with centroids == NULL,

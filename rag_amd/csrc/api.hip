@@ -69,6 +69,25 @@ __global__ void iota_ids_kernel(long long* ids, long long begin, long long end, 
         ids[i] = base + i;
 }
 
+int profile_begin(rag_index* h, hipStream_t s) {
+    if (!h->profiling) return RAG_OK;
+    if (h->prof_used + 2 > h->prof_events.size()) {
+        for (int i = 0; i < 2; ++i) {
+            hipEvent_t e;
+            RAG_HIP_CHECK(hipEventCreate(&e));
+            h->prof_events.push_back(e);
+        }
+    }
+    RAG_HIP_CHECK(hipEventRecord(h->prof_events[h->prof_used], s));
+    return RAG_OK;
+}
+int profile_end(rag_index* h, hipStream_t s) {
+    if (!h->profiling) return RAG_OK;
+    RAG_HIP_CHECK(hipEventRecord(h->prof_events[h->prof_used + 1], s));
+    h->prof_used += 2;
+    return RAG_OK;
+}
+
 static int grid_for(long long n, int block = 256, int maxb = 4096) {
     long long b = (n + block - 1) / block;
     if (b < 1) b = 1;
@@ -176,7 +195,9 @@ static int flat_scan_search(rag_index* h, long long nq, const float* qbuf, int k
         a.nch = 0;
         a.k = k;
         a.capw = 0;
+        if (int rc = profile_begin(h, s)) return rc;
         RAG_HIP_CHECK(launch_flat_scan(a, g, blocks, s));
+        if (int rc = profile_end(h, s)) return rc;
         MergeArgs m;
         m.keys = part;
         m.per_query = (long long)waves * k;
@@ -250,6 +271,7 @@ int rag_index_free(rag_index_t* h) {
     if (h->X && !h->adopted) (void)hipFree(h->X);
     if (h->ids_dev) (void)hipFree(h->ids_dev);
     if (h->active) (void)hipFree(h->active);
+    for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
     ivf_free(h);
     h->ws.release();
     h->ws2.release();
@@ -325,6 +347,28 @@ int rag_index_adopt_device(rag_index_t* h, int64_t n, float* x_dev) {
     h->n = n;
     h->cap = n;
     h->adopted = true;
+    return RAG_OK;
+}
+
+int rag_index_profile_enable(rag_index_t* h, int enable) {
+    if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
+    h->profiling = enable != 0;
+    return RAG_OK;
+}
+
+int rag_index_profile_read(rag_index_t* h, double* kernel_ms, int64_t* launches, int reset) {
+    if (!h || !kernel_ms || !launches) return fail(RAG_ERR_INVALID, "NULL argument");
+    DeviceGuard g(h->device);
+    double total = 0.0;
+    for (size_t i = 0; i + 1 < h->prof_used; i += 2) {
+        RAG_HIP_CHECK(hipEventSynchronize(h->prof_events[i + 1]));
+        float ms = 0.f;
+        RAG_HIP_CHECK(hipEventElapsedTime(&ms, h->prof_events[i], h->prof_events[i + 1]));
+        total += ms;
+    }
+    *kernel_ms = total;
+    *launches = (int64_t)(h->prof_used / 2);
+    if (reset) h->prof_used = 0;
     return RAG_OK;
 }
 
@@ -459,8 +503,11 @@ int rag_index_search(rag_index_t* h, int64_t nq, const float* q, int k, float mi
     return RAG_OK;
 }
 
-int rag_merge_topk_device(int nlists, int64_t nq, int k, const float* D_dev, const int64_t* I_dev, float* D_out_dev,
-                          int64_t* I_out_dev, int device, void* stream) {
+int rag_merge_topk_device(int nlists, int64_t nq, int k, const float* D_dev, int64_t d_list_stride, const int64_t* I_dev,
+                          int64_t i_list_stride, float* D_out_dev, int64_t* I_out_dev, int device, void* stream) {
+    if (d_list_stride == 0) d_list_stride = nq * k;
+    if (i_list_stride == 0) i_list_stride = nq * k;
+    if (d_list_stride < nq * k || i_list_stride < nq * k) return fail(RAG_ERR_INVALID, "list stride smaller than nq*k");
     if (nlists < 1 || nq < 0 || k < 1 || k > 1024) return fail(RAG_ERR_INVALID, "bad nlists / nq / k");
     if (nq == 0) return RAG_OK;
     if (!D_dev || !I_dev || !D_out_dev || !I_out_dev) return fail(RAG_ERR_INVALID, "NULL buffer");
@@ -472,7 +519,7 @@ int rag_merge_topk_device(int nlists, int64_t nq, int k, const float* D_dev, con
     Workspace& ws = keyws[device & 63];
     if (int rc = ws.ensure((size_t)nq * nlists * k * sizeof(u64))) return rc;
     u64* keys = static_cast<u64*>(ws.ptr);
-    RAG_HIP_CHECK(launch_lists_to_keys(nlists, nq, k, D_dev, reinterpret_cast<const long long*>(I_dev), keys, s));
+    RAG_HIP_CHECK(launch_lists_to_keys(nlists, nq, k, D_dev, d_list_stride, reinterpret_cast<const long long*>(I_dev), i_list_stride, keys, s));
     MergeArgs m;
     m.keys = keys;
     m.per_query = (long long)nlists * k;
@@ -481,8 +528,8 @@ int rag_merge_topk_device(int nlists, int64_t nq, int k, const float* D_dev, con
     m.min_score = -FLT_MAX;
     m.row_ids = nullptr;
     m.id_base = 0;
-    m.slot_ids = reinterpret_cast<const long long*>(I_dev);   // [nlists][nq][k]
-    m.slot_stride = nq;
+    m.slot_ids = reinterpret_cast<const long long*>(I_dev);
+    m.slot_stride = i_list_stride;
     m.D = D_out_dev;
     m.I = reinterpret_cast<long long*>(I_out_dev);
     RAG_HIP_CHECK(launch_merge_keys(m, nq, s));

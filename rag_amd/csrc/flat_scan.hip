@@ -264,9 +264,9 @@ __global__ __launch_bounds__(1024) void merge_keys_kernel(MergeArgs a) {
             if (sc >= a.min_score) {
                 const uint32_t slot = key_row(key);
                 s = sc;
-                if (a.slot_ids) {   // merge of finished lists [nlists][nq][k]: slot = list*k + rank
+                if (a.slot_ids) {   // merge of finished lists: slot = list*k + rank
                     const uint32_t g = slot / (uint32_t)k, j = slot % (uint32_t)k;
-                    id = a.slot_ids[((size_t)g * a.slot_stride + q) * k + j];
+                    id = a.slot_ids[(size_t)g * a.slot_stride + (size_t)q * k + j];
                 }
                 else if (a.row_ids) id = a.row_ids[slot];
                 else id = a.id_base + (long long)slot;
@@ -277,16 +277,19 @@ __global__ __launch_bounds__(1024) void merge_keys_kernel(MergeArgs a) {
     }
 }
 
-// (D, I) result lists -> keys whose "row" is the slot in the gathered list
-// [nlists][nq][k] -> keys [nq][nlists*k]; an unfilled slot (I < 0) gives no key.
-__global__ void lists_to_keys_kernel(int nlists, long long nq, int k, const float* D, const long long* I, u64* keys) {
+// (D, I) result lists -> keys whose "row" is the slot (list*k + rank) in the
+// gathered set; output keys [nq][nlists*k]; an unfilled slot (I < 0) gives no key.
+__global__ void lists_to_keys_kernel(int nlists, long long nq, int k, const float* D, long long d_stride,
+                                     const long long* I, long long i_stride, u64* keys) {
     const long long total = (long long)nlists * nq * k;
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
         const int j = (int)(t % k);
         const long long q = (t / k) % nq;
         const int g = (int)(t / ((long long)k * nq));
         const uint32_t slot = (uint32_t)(g * k + j);
-        keys[(size_t)q * nlists * k + slot] = (I[t] < 0) ? KEY_EMPTY : make_key(D[t], slot);
+        const long long id = I[(size_t)g * i_stride + (size_t)q * k + j];
+        const float sc = D[(size_t)g * d_stride + (size_t)q * k + j];
+        keys[(size_t)q * nlists * k + slot] = (id < 0) ? KEY_EMPTY : make_key(sc, slot);
     }
 }
 
@@ -410,10 +413,11 @@ hipError_t launch_merge_keys(const MergeArgs& a, long long nq, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_lists_to_keys(int nlists, long long nq, int k, const float* D, const long long* I, u64* keys, hipStream_t s) {
+hipError_t launch_lists_to_keys(int nlists, long long nq, int k, const float* D, long long d_stride, const long long* I,
+                                long long i_stride, u64* keys, hipStream_t s) {
     const long long total = (long long)nlists * nq * k;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(lists_to_keys_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, nlists, nq, k, D, I, keys);
+    hipLaunchKernelGGL(lists_to_keys_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, nlists, nq, k, D, d_stride, I, i_stride, keys);
     return hipGetLastError();
 }
 

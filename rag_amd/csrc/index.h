@@ -9,6 +9,8 @@
 #include "../../include/rag_hip.h"
 #include "kernels.h"
 
+struct rag_index;
+
 namespace rag {
 
 void set_error(const std::string& msg);
@@ -29,6 +31,10 @@ struct Workspace {
     int ensure(size_t need);   // returns rag_status
     void release();
 };
+
+// RAII-free helpers: record an event pair around a launch when profiling is on
+int profile_begin(rag_index* h, hipStream_t s);
+int profile_end(rag_index* h, hipStream_t s);
 
 struct IvfState {
     int nlist = 0;
@@ -63,4 +69,8 @@ struct rag_index {
     hipStream_t stream = nullptr;   // used by the host-pointer entry points
     const char* last_path = "none";
     rag::IvfState ivf;
+    // measurement: event pairs around the dominant kernel of each search
+    bool profiling = false;
+    std::vector<hipEvent_t> prof_events;   // start, stop, start, stop, ...
+    size_t prof_used = 0;
 };

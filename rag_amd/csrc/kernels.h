@@ -28,8 +28,8 @@ struct MergeArgs {
     float min_score;
     const long long* row_ids;    // nullptr: id = id_base + row
     long long id_base;
-    const long long* slot_ids;   // merge of finished lists [nlists][nq][k]: slot = list*k + rank
-    long long slot_stride;       //   = nq
+    const long long* slot_ids;   // merge of finished lists: slot = list*k + rank lives at
+    long long slot_stride;       //   slot_ids[list*slot_stride + q*k + rank]
     float* D;                    // [nq][k]
     long long* I;                // [nq][k]
 };
@@ -38,7 +38,8 @@ int scan_rows_per_tile(int d4);
 int scan_lanes_per_row(int d4);
 hipError_t launch_flat_scan(ScanArgs a, int nq, int blocks, hipStream_t s);
 hipError_t launch_merge_keys(const MergeArgs& a, long long nq, hipStream_t s);
-hipError_t launch_lists_to_keys(int nlists, long long nq, int k, const float* D, const long long* I, u64* keys, hipStream_t s);
+hipError_t launch_lists_to_keys(int nlists, long long nq, int k, const float* D, long long d_stride, const long long* I,
+                                long long i_stride, u64* keys, hipStream_t s);
 hipError_t launch_prep_queries(const float* q, long long nq, int d, int ld, int normalize, float* out, hipStream_t s);
 hipError_t launch_ingest_rows(const float* src, long long n, int d, int ld, int normalize, float* dst, hipStream_t s);
 hipError_t launch_gather_rows(const float* X, int d, int ld, long long n, const long long* rows, long long ntotal, float* out, hipStream_t s);

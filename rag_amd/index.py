@@ -70,6 +70,16 @@ class DeviceIndex:
     def last_path(self) -> str:
         return (lib.rag_index_last_path(self._h) or b"").decode()
 
+    # --------------------------------------------------------------- measurement
+    def profile(self, enable: bool = True) -> None:
+        check(lib.rag_index_profile_enable(self._h, 1 if enable else 0))
+
+    def profile_read(self, reset: bool = True):
+        """(summed dominant-kernel milliseconds, launches) since the last reset."""
+        ms, n = C.c_double(0.0), C.c_int64(0)
+        check(lib.rag_index_profile_read(self._h, C.byref(ms), C.byref(n), 1 if reset else 0))
+        return ms.value, n.value
+
     # -------------------------------------------------------------------- ingest
     def reserve(self, nrows: int) -> None:
         check(lib.rag_index_reserve(self._h, int(nrows)))
@@ -195,7 +205,7 @@ def merge_topk(D, I, device: Optional[int] = None):
     Do = torch.empty((nq, k), dtype=torch.float32, device=D.device)
     Io = torch.empty((nq, k), dtype=torch.int64, device=D.device)
     stream = torch.cuda.current_stream(D.device).cuda_stream
-    check(lib.rag_merge_topk_device(nl, nq, k, C.c_void_p(D.data_ptr()), C.c_void_p(I.data_ptr()),
+    check(lib.rag_merge_topk_device(nl, nq, k, C.c_void_p(D.data_ptr()), 0, C.c_void_p(I.data_ptr()), 0,
                                     C.c_void_p(Do.data_ptr()), C.c_void_p(Io.data_ptr()), dev,
                                     C.c_void_p(stream)))
     return Do, Io
