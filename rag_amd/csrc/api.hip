@@ -2,6 +2,7 @@
 // The declarations (and the reference interfaces they stand in for) are in
 // include/rag_hip.h.
 #include <float.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -153,16 +154,23 @@ void ivf_free(rag_index* h);
 int gemm_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask,
                      float* D, long long* I, hipStream_t s);                 // gemm_topk.hip
 bool gemm_topk_supported(const rag_index* h, long long nq, int k);
+size_t gemm_topk_workspace(const rag_index* h, long long nq, int k);
+
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
 
 // blocks for the scan: enough waves to fill the chip, not more lists than rows justify
 static int scan_blocks(const rag_index* h) {
+    static const int max_blocks = env_int("RAG_SCAN_BLOCKS", 1024);
     const int tile = scan_rows_per_tile(h->ld / 4);
     const long long ntiles = (h->n + tile - 1) / tile;
     // at least ~64 tiles per wave before adding another wave; at most 4 blocks per CU
     long long waves = (ntiles + 63) / 64;
     long long blocks = (waves + 3) / 4;
     if (blocks < 1) blocks = 1;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > max_blocks) blocks = max_blocks;
     return (int)blocks;
 }
 
@@ -195,6 +203,9 @@ static int flat_scan_search(rag_index* h, long long nq, const float* qbuf, int k
         a.nch = 0;
         a.k = k;
         a.capw = 0;
+        // rows larger than the Infinity Cache are streamed; smaller corpora stay cacheable
+        static const int nt_mode = env_int("RAG_SCAN_NT", -1);
+        a.nt = nt_mode >= 0 ? nt_mode : ((size_t)h->n * h->ld * sizeof(float) > (192ull << 20) ? 1 : 0);
         if (int rc = profile_begin(h, s)) return rc;
         RAG_HIP_CHECK(launch_flat_scan(a, g, blocks, s));
         if (int rc = profile_end(h, s)) return rc;
@@ -451,25 +462,20 @@ int rag_index_search_device(rag_index_t* h, int64_t nq, const float* q_dev, int 
             mask = h->active;
         }
     }
-    // padded (and for COSINE normalised) queries at the start of the workspace
+    // workspace = [padded queries | what the chosen kernel needs]; sized before anything is
+    // enqueued, because growing it frees the old allocation
     const size_t qbytes = ((size_t)nq * h->ld * sizeof(float) + 255) & ~(size_t)255;
-    if (int rc = h->ws.ensure(qbytes)) return rc;
+    const bool use_gemm = h->kind == RAG_KIND_FLAT && gemm_topk_supported(h, nq, k);
+    size_t extra = 0;
+    if (use_gemm) extra = gemm_topk_workspace(h, nq, k);
+    else if (h->kind == RAG_KIND_FLAT) extra = (size_t)((k > 64) ? 1 : 8) * scan_blocks(h) * 4 * k * sizeof(u64);
+    if (int rc = h->ws.ensure(qbytes + extra)) return rc;
+    // padded (and for COSINE normalised) queries at the start of the workspace
     RAG_HIP_CHECK(launch_prep_queries(q_dev, nq, h->dim, h->ld, h->metric == RAG_METRIC_COSINE, static_cast<float*>(h->ws.ptr), s));
-    if (h->kind == RAG_KIND_IVF) {
+    if (h->kind == RAG_KIND_IVF)
         return ivf_search_device(h, nq, static_cast<const float*>(h->ws.ptr), k, min_score, nprobe, mask, D_dev, I, s);
-    }
-    if (gemm_topk_supported(h, nq, k)) {
+    if (use_gemm)
         return gemm_topk_search(h, nq, static_cast<const float*>(h->ws.ptr), k, min_score, mask, D_dev, I, s);
-    }
-    // ws.ensure inside flat_scan_search may move the workspace: grow it first, then re-prep if it moved
-    {
-        const int blocks = scan_blocks(h);
-        const size_t pbytes = (size_t)((k > 64) ? 1 : 8) * blocks * 4 * k * sizeof(u64);
-        void* before = h->ws.ptr;
-        if (int rc = h->ws.ensure(qbytes + pbytes)) return rc;
-        if (h->ws.ptr != before)
-            RAG_HIP_CHECK(launch_prep_queries(q_dev, nq, h->dim, h->ld, h->metric == RAG_METRIC_COSINE, static_cast<float*>(h->ws.ptr), s));
-    }
     return flat_scan_search(h, nq, static_cast<const float*>(h->ws.ptr), k, min_score, mask, D_dev, I, s);
 }
 

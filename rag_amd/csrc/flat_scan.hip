@@ -43,7 +43,15 @@ __device__ __forceinline__ f4 f4_zero() { return (f4){0.f, 0.f, 0.f, 0.f}; }
 // U    wave steps per tile (rows in flight per wave = U*RPS)
 // NQ   queries scored against every row (1: query fragment in registers; >1: LDS)
 // BIGK false: register list (k <= 64); true: LDS buffer (NQ must be 1)
-template <int LPR, int CH, int U, int NQ, bool BIGK>
+template <bool NT>
+__device__ __forceinline__ f4 load_row4(const f4* p) {
+    // rows are read once per launch: a non-temporal load keeps them from
+    // displacing the queries and partial lists in L2 / Infinity Cache
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+
+template <int LPR, int CH, int U, int NQ, bool BIGK, bool NT>
 __global__ __launch_bounds__(256) void flat_scan_kernel(ScanArgs a) {
     constexpr int RPS = 64 / LPR;
     constexpr int TILE = RPS * U;
@@ -122,7 +130,7 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(ScanArgs a) {
 #pragma unroll
                 for (int c = 0; c < CH; ++c) {
                     const int col = c * LPR + l;
-                    x[u][c] = (col < d4) ? xr[col] : f4_zero();
+                    x[u][c] = (col < d4) ? load_row4<NT>(xr + col) : f4_zero();
                 }
             }
 #pragma unroll
@@ -149,7 +157,7 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(ScanArgs a) {
                 for (int u = 0; u < U; ++u) {
                     long long r = row0 + u * RPS + sub;
                     r = r < a.n ? r : a.n - 1;
-                    x[u] = in ? X4[r * (long long)d4 + col] : f4_zero();
+                    x[u] = in ? load_row4<NT>(X4 + r * (long long)d4 + col) : f4_zero();
                 }
 #pragma unroll
                 for (int qi = 0; qi < NQ; ++qi) {
@@ -342,15 +350,21 @@ __global__ void gather_rows_kernel(const float* X, int d, int ld, long long n, c
 
 // ---------------------------------------------------------------------------
 // host-side launchers
-template <int LPR, int CH, int U, int NQ, bool BIGK>
-static hipError_t launch_scan_t(const ScanArgs& a, int blocks, size_t lds, hipStream_t s) {
-    auto kern = flat_scan_kernel<LPR, CH, U, NQ, BIGK>;
+template <int LPR, int CH, int U, int NQ, bool BIGK, bool NT>
+static hipError_t launch_scan_t2(const ScanArgs& a, int blocks, size_t lds, hipStream_t s) {
+    auto kern = flat_scan_kernel<LPR, CH, U, NQ, BIGK, NT>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, a);
     return hipGetLastError();
+}
+
+template <int LPR, int CH, int U, int NQ, bool BIGK>
+static hipError_t launch_scan_t(const ScanArgs& a, int blocks, size_t lds, hipStream_t s) {
+    return a.nt ? launch_scan_t2<LPR, CH, U, NQ, BIGK, true>(a, blocks, lds, s)
+                : launch_scan_t2<LPR, CH, U, NQ, BIGK, false>(a, blocks, lds, s);
 }
 
 template <int NQ, bool BIGK>

@@ -18,6 +18,7 @@ struct ScanArgs {
     int nch;               // chunks per lane per row (run-time variant)
     int k;
     int capw;              // k > 64: keys per wave-private LDS buffer
+    int nt;                // 1: non-temporal row loads
 };
 
 struct MergeArgs {

@@ -4,8 +4,6 @@ namespace rag {
 int ivf_assign_new_rows(rag_index*, long long, long long) { return fail(RAG_ERR_UNSUPPORTED, "IVF not built"); }
 int ivf_search_device(rag_index*, long long, const float*, int, float, int, const uint8_t*, float*, long long*, hipStream_t) { return fail(RAG_ERR_UNSUPPORTED, "IVF not built"); }
 void ivf_free(rag_index*) {}
-int gemm_topk_search(rag_index*, long long, const float*, int, float, const uint8_t*, float*, long long*, hipStream_t) { return fail(RAG_ERR_UNSUPPORTED, "gemm path not built"); }
-bool gemm_topk_supported(const rag_index*, long long, int) { return false; }
 }
 using namespace rag;
 extern "C" {
