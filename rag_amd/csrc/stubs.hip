@@ -8,8 +8,4 @@ void ivf_free(rag_index*) {}
 using namespace rag;
 extern "C" {
 int rag_index_train_ivf(rag_index_t*, int, const float*, int64_t, const float*) { return fail(RAG_ERR_UNSUPPORTED, "IVF not built"); }
-int rag_fuse_weighted(int64_t, const double*, const double*, double, double, int, double, int, int32_t*, double*, int32_t*) { return fail(RAG_ERR_UNSUPPORTED, "fusion not built"); }
-int rag_fuse_maxnorm(int64_t, const double*, const double*, const uint8_t*, const uint8_t*, double, double, double, double, int, int32_t*, double*, double*, double*, int32_t*) { return fail(RAG_ERR_UNSUPPORTED, "fusion not built"); }
-int rag_mmr_select(int64_t, int, const void*, int, const double*, double, double, int, int, int, int32_t*, int32_t*) { return fail(RAG_ERR_UNSUPPORTED, "mmr not built"); }
-int rag_mmr_select_rows(rag_index_t*, int64_t, const int64_t*, const double*, double, double, int, int, int32_t*, int32_t*) { return fail(RAG_ERR_UNSUPPORTED, "mmr not built"); }
 }
