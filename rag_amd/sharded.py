@@ -65,12 +65,13 @@ class ShardedIndex:
         packed = torch.empty((2, nq, k), dtype=torch.int64, device=D.device)
         packed[0] = I
         packed[1] = D.contiguous().view(torch.int32).to(torch.int64)
-        shape = (self.world, 2, nq, k)
+        shape = (self.world * 2, nq, k)          # rank r's block lands at [2r, 2r + 2)
         if self._gather_buf is None or self._gather_buf.shape != shape or self._gather_buf.device != D.device:
             self._gather_buf = torch.empty(shape, dtype=torch.int64, device=D.device)
         self.dist.all_gather_into_tensor(self._gather_buf, packed, group=self.group)
-        I_all = self._gather_buf[:, 0].contiguous()
-        D_all = self._gather_buf[:, 1].to(torch.int32).view(torch.float32).contiguous()
+        gathered = self._gather_buf.view(self.world, 2, nq, k)
+        I_all = gathered[:, 0].contiguous()
+        D_all = gathered[:, 1].to(torch.int32).view(torch.float32).contiguous()
         Dm, Im = self._merge(D_all, I_all)
         if was_numpy:
             return Dm.cpu().numpy(), Im.cpu().numpy()

@@ -1,0 +1,95 @@
+"""CPU-only checks: the C ABI library loads and exports every declared symbol,
+host-side logic (BM25, relevance normalisation, sharding) matches the golden
+vectors, and the product path refuses to run without a GPU instead of falling
+back to anything."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "rag_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(rag_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    from rag_amd import _lib
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.rag_version() == 1
+
+
+def test_no_oracle_import_in_product_code():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "rag_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from rag_amd import DeviceIndex, RagHipError
+    with pytest.raises(RagHipError):
+        DeviceIndex(16, metric="ip")
+    from rag_amd import fusion
+    with pytest.raises(RagHipError):
+        fusion.fuse_weighted([0.5], [0.25], 0.7, 0.3, None, 1)
+    from rag_amd.mmr_diversifier import MMRDiversifier
+    with pytest.raises(RagHipError):
+        MMRDiversifier().diversify_sync([{"score": 1.0, "embedding": [1.0, 0.0]}, {"score": 0.5, "embedding": [0.0, 1.0]}])
+
+
+def test_bm25_host_logic_matches_reference(golden):
+    from rag_amd.bm25 import CorpusStatsManager
+    data = golden("bm25.json")
+    c = CorpusStatsManager()
+    for q, exp in data["preprocess"]:
+        assert c.preprocess_query(q) == exp
+    st = c.compute_corpus_stats(data["corpus"])
+    assert st["total_docs"] == data["stats"]["total_docs"]
+    assert st["avg_doc_length"] == data["stats"]["avg_doc_length"]
+    assert dict(st["idf"]) == data["stats"]["idf"]
+    for case in data["scores"]:
+        stats = case["stats"] if case["stats"] is not None else st
+        assert c.calculate_bm25_score(case["terms"], case["text"], stats) == case["expected"]
+    for case in data["normalize"]:
+        assert c.normalize_scores(case["scores"], case["method"]) == case["expected"]
+    from oracle import bm25 as obm
+    texts = data["corpus"]
+    assert c.keyword_rank("dense retrieval search", texts, texts, 3) == obm.keyword_rank("dense retrieval search", texts, texts, 3)
+
+
+def test_relevance_normalisation_and_schemas():
+    from rag_amd.mmr_diversifier import MMRDiversifier, create_balanced_mmr, normalise_relevance
+    from rag_amd.schemas import SearchFilters, SearchResult
+    assert normalise_relevance([0.5, 2.0, 1.25]) == [0.0, 1.0, 0.5]
+    assert normalise_relevance([3.0, 3.0]) == [1.0, 1.0] and normalise_relevance([]) == []
+    with pytest.raises(ValueError):
+        MMRDiversifier(lambda_param=1.5)
+    assert create_balanced_mmr().lambda_param == 0.6
+    f = SearchFilters()
+    assert (f.mmr_lambda, f.mmr_similarity_threshold, f.mmr_similarity_metric) == (0.6, 0.8, "cosine")
+    with pytest.raises(ValueError):
+        SearchFilters(mmr_similarity_metric="manhattan")
+    r = SearchResult(document_id=1, chunk_id="c", text="t", score=0.5, metadata={"a": 1})
+    assert SearchResult.from_dict(r.to_dict()) == r
+    # no-embedding path answers the first results without touching the GPU (mmr_diversifier.py:170-172)
+    assert MMRDiversifier().diversify_sync([{"score": 0.1}, {"score": 0.9}], max_results=1) == [{"score": 0.1}]
+
+
+def test_shard_range_covers_rows_once():
+    from rag_amd.sharded import shard_range
+    for n, w in ((10_000_000, 8), (100, 3), (7, 8), (0, 2), (12_345_678, 4)):
+        spans = [shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        for (a, b), (c, d) in zip(spans, spans[1:]):
+            assert b == c and a <= b
