@@ -151,10 +151,12 @@ int ivf_assign_new_rows(rag_index* h, long long first, long long count);   // iv
 int ivf_search_device(rag_index* h, long long nq, const float* qbuf, int k, float min_score, int nprobe,
                       const uint8_t* mask, float* D, long long* I, hipStream_t s);
 void ivf_free(rag_index* h);
+size_t ivf_search_workspace(const rag_index* h, long long nq, int k, int nprobe);
 int gemm_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask,
                      float* D, long long* I, hipStream_t s);                 // gemm_topk.hip
 bool gemm_topk_supported(const rag_index* h, long long nq, int k);
 size_t gemm_topk_workspace(const rag_index* h, long long nq, int k);
+int ivf_reconstruct_rows(rag_index* h, long long n, const int64_t* rows, std::vector<long long>& storage_rows);
 
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
@@ -173,6 +175,8 @@ static int scan_blocks(const rag_index* h) {
     if (blocks > max_blocks) blocks = max_blocks;
     return (int)blocks;
 }
+
+size_t flat_search_workspace(const rag_index* h, long long nq, int k);
 
 static int flat_scan_search(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask,
                             float* D, long long* I, hipStream_t s) {
@@ -203,6 +207,12 @@ static int flat_scan_search(rag_index* h, long long nq, const float* qbuf, int k
         a.nch = 0;
         a.k = k;
         a.capw = 0;
+        a.ivf_lists = nullptr;
+        a.list_begin = nullptr;
+        a.row_alias = nullptr;
+        a.ivf_nprobe = 0;
+        a.ivf_slices = 1;
+        a.grid_y = 1;
         // rows larger than the Infinity Cache are streamed; smaller corpora stay cacheable
         static const int nt_mode = env_int("RAG_SCAN_NT", -1);
         a.nt = nt_mode >= 0 ? nt_mode : ((size_t)h->n * h->ld * sizeof(float) > (192ull << 20) ? 1 : 0);
@@ -226,6 +236,23 @@ static int flat_scan_search(rag_index* h, long long nq, const float* qbuf, int k
     }
     h->last_path = "scan";
     return RAG_OK;
+}
+
+// bytes the exhaustive search needs in h->ws after the padded queries
+size_t flat_search_workspace(const rag_index* h, long long nq, int k) {
+    if (gemm_topk_supported(h, nq, k)) return gemm_topk_workspace(h, nq, k);
+    return (size_t)((k > 64) ? 1 : 8) * scan_blocks(h) * 4 * k * sizeof(u64);
+}
+
+// exhaustive search of queries that are already padded to h->ld (and normalised if
+// the metric asks for it).  qbuf may lie at the start of h->ws, in which case the
+// caller has sized the workspace with flat_search_workspace() beforehand.
+int flat_search_prepared(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask,
+                         float* D, long long* I, hipStream_t s) {
+    const size_t qbytes = ((size_t)nq * h->ld * sizeof(float) + 255) & ~(size_t)255;
+    if (int rc = h->ws.ensure(qbytes + flat_search_workspace(h, nq, k))) return rc;
+    if (gemm_topk_supported(h, nq, k)) return gemm_topk_search(h, nq, qbuf, k, min_score, mask, D, I, s);
+    return flat_scan_search(h, nq, qbuf, k, min_score, mask, D, I, s);
 }
 
 }  // namespace rag
@@ -425,7 +452,14 @@ int rag_index_reconstruct(rag_index_t* h, int64_t n, const int64_t* rows, float*
     if (int rc = h->ws2.ensure(rbytes + (size_t)n * h->dim * sizeof(float))) return rc;
     long long* drows = static_cast<long long*>(h->ws2.ptr);
     float* dout = reinterpret_cast<float*>(static_cast<char*>(h->ws2.ptr) + rbytes);
-    RAG_HIP_CHECK(hipMemcpyAsync(drows, rows, (size_t)n * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+    std::vector<long long> storage_rows;
+    const void* src_rows = rows;
+    if (h->kind == RAG_KIND_IVF) {
+        if (int rc = ivf_reconstruct_rows(h, n, rows, storage_rows)) return rc;
+        src_rows = storage_rows.data();
+    }
+    RAG_HIP_CHECK(hipMemcpyAsync(drows, src_rows, (size_t)n * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+    RAG_HIP_CHECK(hipStreamSynchronize(h->stream));
     RAG_HIP_CHECK(launch_gather_rows(h->X, h->dim, h->ld, n, drows, h->n, dout, h->stream));
     RAG_HIP_CHECK(hipMemcpyAsync(out, dout, (size_t)n * h->dim * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     RAG_HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -465,18 +499,13 @@ int rag_index_search_device(rag_index_t* h, int64_t nq, const float* q_dev, int 
     // workspace = [padded queries | what the chosen kernel needs]; sized before anything is
     // enqueued, because growing it frees the old allocation
     const size_t qbytes = ((size_t)nq * h->ld * sizeof(float) + 255) & ~(size_t)255;
-    const bool use_gemm = h->kind == RAG_KIND_FLAT && gemm_topk_supported(h, nq, k);
-    size_t extra = 0;
-    if (use_gemm) extra = gemm_topk_workspace(h, nq, k);
-    else if (h->kind == RAG_KIND_FLAT) extra = (size_t)((k > 64) ? 1 : 8) * scan_blocks(h) * 4 * k * sizeof(u64);
+    const size_t extra = h->kind == RAG_KIND_FLAT ? flat_search_workspace(h, nq, k) : ivf_search_workspace(h, nq, k, nprobe);
     if (int rc = h->ws.ensure(qbytes + extra)) return rc;
     // padded (and for COSINE normalised) queries at the start of the workspace
     RAG_HIP_CHECK(launch_prep_queries(q_dev, nq, h->dim, h->ld, h->metric == RAG_METRIC_COSINE, static_cast<float*>(h->ws.ptr), s));
     if (h->kind == RAG_KIND_IVF)
         return ivf_search_device(h, nq, static_cast<const float*>(h->ws.ptr), k, min_score, nprobe, mask, D_dev, I, s);
-    if (use_gemm)
-        return gemm_topk_search(h, nq, static_cast<const float*>(h->ws.ptr), k, min_score, mask, D_dev, I, s);
-    return flat_scan_search(h, nq, static_cast<const float*>(h->ws.ptr), k, min_score, mask, D_dev, I, s);
+    return flat_search_prepared(h, nq, static_cast<const float*>(h->ws.ptr), k, min_score, mask, D_dev, I, s);
 }
 
 int rag_index_search(rag_index_t* h, int64_t nq, const float* q, int k, float min_score, int nprobe,

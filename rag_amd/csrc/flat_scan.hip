@@ -67,7 +67,26 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(ScanArgs a) {
     const int d4 = a.d4;
     const int nch = CH ? CH : a.nch;
     const f4* __restrict__ X4 = reinterpret_cast<const f4*>(a.X);
-    const f4* __restrict__ Q4 = reinterpret_cast<const f4*>(a.Q);
+    const f4* __restrict__ Q4 = reinterpret_cast<const f4*>(a.Q) + (size_t)blockIdx.y * d4 * NQ;
+
+    // rows this wave walks: tiles t0, t0 + tstride, ... of [r_begin, r_end).
+    //   exhaustive: the whole corpus, tiles dealt round-robin over every wave of the grid
+    //   IVF: blockIdx.y = query, blockIdx.x = (probed list, slice of the list); the
+    //        block's four waves share the slice
+    long long r_begin = 0, r_end = a.n, t0 = w, tstride = nwaves;
+    if (a.ivf_lists) {
+        const int probe = blockIdx.x / a.ivf_slices, slice = blockIdx.x % a.ivf_slices;
+        const long long lst = a.ivf_lists[(size_t)blockIdx.y * a.ivf_nprobe + probe];
+        long long lb = 0, le = 0;
+        if (lst >= 0) { lb = a.list_begin[lst]; le = a.list_begin[lst + 1]; }
+        const long long ltiles = (le - lb + TILE - 1) / TILE;
+        r_begin = lb + (ltiles * slice / a.ivf_slices) * TILE;
+        const long long e = lb + (ltiles * (slice + 1) / a.ivf_slices) * TILE;
+        r_end = e < le ? e : le;
+        if (r_end < r_begin) r_end = r_begin;
+        t0 = wib;
+        tstride = 4;
+    }
 
     // ---- query fragments --------------------------------------------------
     constexpr int QREG = (NQ == 1 && CH > 0) ? CH : 1;
@@ -102,9 +121,9 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(ScanArgs a) {
     for (int qi = 0; qi < NQ; ++qi) { list[qi] = KEY_EMPTY; thr[qi] = KEY_EMPTY; thr_f[qi] = -INFINITY; }
     const int k = a.k;
 
-    const long long ntiles = (a.n + TILE - 1) / TILE;
-    for (long long tile = w; tile < ntiles; tile += nwaves) {
-        const long long row0 = tile * TILE;
+    const long long ntiles = (r_end - r_begin + TILE - 1) / TILE;
+    for (long long tile = t0; tile < ntiles; tile += tstride) {
+        const long long row0 = r_begin + tile * TILE;
         float acc[U][NQ];
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -115,7 +134,7 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(ScanArgs a) {
         bool rv = false;
         if (lane < TILE) {
             const long long r = row0 + lane;
-            rv = r < a.n;
+            rv = r < r_end;
             if (rv && a.mask) rv = a.mask[r] != 0;
         }
         const u64 rowvalid = __ballot(rv);
@@ -125,7 +144,7 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(ScanArgs a) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 long long r = row0 + u * RPS + sub;
-                r = r < a.n ? r : a.n - 1;
+                r = r < r_end ? r : r_end - 1;
                 const f4* xr = X4 + r * (long long)d4;
 #pragma unroll
                 for (int c = 0; c < CH; ++c) {
@@ -156,7 +175,7 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(ScanArgs a) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     long long r = row0 + u * RPS + sub;
-                    r = r < a.n ? r : a.n - 1;
+                    r = r < r_end ? r : r_end - 1;
                     x[u] = in ? load_row4<NT>(X4 + r * (long long)d4 + col) : f4_zero();
                 }
 #pragma unroll
@@ -188,8 +207,9 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(ScanArgs a) {
                     const int j = __builtin_ctzll(m);
                     m &= m - 1;
                     const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc[u][qi]), j));
-                    const uint32_t row = (uint32_t)(row0 + u * RPS + j / LPR);
-                    const u64 key = make_key(sc, row);
+                    long long rowp = row0 + u * RPS + j / LPR;
+                    if (a.row_alias) rowp = a.row_alias[rowp];      // storage position -> insertion position
+                    const u64 key = make_key(sc, (uint32_t)rowp);
                     if (key > thr[qi]) {
                         if constexpr (!BIGK) {
                             wave_list_insert(list[qi], key, lane);
@@ -214,12 +234,12 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(ScanArgs a) {
     if constexpr (!BIGK) {
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi)
-            if (lane < k) a.part[((size_t)qi * nwaves + w) * k + lane] = list[qi];
+            if (lane < k) a.part[(((size_t)blockIdx.y * NQ + qi) * nwaves + w) * k + lane] = list[qi];
     } else {
         // pad with empties, sort, write the first k
         for (int i = cnt + lane; i < capw; i += 64) wbuf[i] = KEY_EMPTY;
         bitonic_sort_desc_lds(wbuf, capw, lane, 64, SyncWave());
-        for (int i = lane; i < k; i += 64) a.part[(size_t)w * k + i] = wbuf[i];
+        for (int i = lane; i < k; i += 64) a.part[((size_t)blockIdx.y * nwaves + w) * k + i] = wbuf[i];
     }
 }
 
@@ -357,7 +377,7 @@ static hipError_t launch_scan_t2(const ScanArgs& a, int blocks, size_t lds, hipS
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(blocks, a.ivf_lists ? a.grid_y : 1), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 

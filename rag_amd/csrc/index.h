@@ -36,15 +36,19 @@ struct Workspace {
 int profile_begin(rag_index* h, hipStream_t s);
 int profile_end(rag_index* h, hipStream_t s);
 
+// IVF bookkeeping.  Rows are stored grouped by list ("storage order"); ids, the
+// soft-delete bytes and every caller-visible row number stay in insertion order.
 struct IvfState {
     int nlist = 0;
-    float* centroids = nullptr;          // [nlist][ld] device
-    std::vector<long long> list_begin;   // host copy of CSR offsets, nlist + 1
-    long long* list_begin_dev = nullptr;
-    // rows are stored grouped by list: X / row_ids of the index are in list order
-    bool built = false;
-    // rows added since the last build, kept until build() packs them
-    std::vector<int> pending_assign;
+    rag_index* quantizer = nullptr;       // FLAT inner-product index over the centroids
+    std::vector<int> assign;              // insertion position -> list
+    std::vector<long long> orig;          // storage position -> insertion position
+    std::vector<long long> pos;           // insertion position -> storage position
+    long long n_packed = 0;               // rows [0, n_packed) of X are in list order
+    long long* list_begin_dev = nullptr;  // [nlist + 1]
+    long long* orig_dev = nullptr;        // [n_packed]
+    long long orig_cap = 0;
+    Workspace ws;                         // coarse results, packed mask
 };
 
 }  // namespace rag

@@ -1,0 +1,267 @@
+// Inverted-file index with flat (uncompressed) lists and an inner-product coarse
+// quantiser -- FAISS IndexIVFFlat semantics: a row is stored in the list of the
+// centroid with the largest inner product; a search scores the query against all
+// centroids, takes the nprobe best lists and scans only their rows.
+//
+// Both steps reuse the exhaustive kernels.  Coarse assignment and probe selection
+// are top-k searches of (rows | queries) against the centroid table (GEMM path for
+// batches, scan path for single queries).  The list scan is flat_scan_kernel in its
+// per-block row-range mode: blockIdx.y = query, blockIdx.x = (probed list, slice).
+//
+// Storage.  Rows are physically grouped by list so a list is one contiguous HBM
+// range; rows that arrived since the last search sit unsorted at the tail and are
+// folded in (one device gather) by the next search.  Keys carry the INSERTION
+// position (row_alias), so ids, masks, ties and results are the same as for a flat
+// index of the same rows.
+#include <float.h>
+#include <string.h>
+
+#include <algorithm>
+#include <numeric>
+
+#include "index.h"
+#include "topk_keys.h"
+
+namespace rag {
+
+int flat_search_prepared(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask,
+                         float* D, long long* I, hipStream_t s);
+
+__global__ void gather_packed_rows_kernel(const float* src, const long long* src_row, long long n, int ld4, float* dst) {
+    // one wave per destination row
+    const int lane = threadIdx.x & 63;
+    const long long wave = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
+    const long long nw = ((long long)gridDim.x * blockDim.x) >> 6;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4* s4 = reinterpret_cast<const f4*>(src);
+    f4* d4 = reinterpret_cast<f4*>(dst);
+    for (long long r = wave; r < n; r += nw) {
+        const long long sr = src_row[r];
+        for (int c = lane; c < ld4; c += 64) d4[r * ld4 + c] = s4[sr * ld4 + c];
+    }
+}
+
+__global__ void gather_mask_kernel(const uint8_t* mask, const long long* orig, long long n, uint8_t* out) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = mask[orig[i]];
+}
+
+constexpr long long IVF_QCHUNK = 32768;     // queries per launch (grid.y) and workspace bound
+
+// slices per probed list: enough blocks to fill the chip, but a slice keeps >= 32 tiles of
+// an average list
+static long long ivf_slices(const rag_index* h, long long nq, int nprobe) {
+    const int tile = scan_rows_per_tile(h->ld / 4);
+    const long long avg_tiles = std::max<long long>(1, (h->n / std::max(1, h->ivf.nlist)) / tile);
+    long long slices = 2048 / std::max<long long>(1, nq * nprobe);
+    slices = std::min<long long>(slices, std::max<long long>(1, avg_tiles / 32));
+    return slices < 1 ? 1 : slices;
+}
+
+// bytes the list scan needs in h->ws after the padded queries
+size_t ivf_search_workspace(const rag_index* h, long long nq, int k, int nprobe) {
+    if (nprobe > h->ivf.nlist) nprobe = h->ivf.nlist;
+    if (nprobe < 1) nprobe = 1;
+    const long long waves = (long long)nprobe * ivf_slices(h, nq, nprobe) * 4;
+    return (size_t)std::min(nq, IVF_QCHUNK) * waves * k * sizeof(u64);
+}
+
+void ivf_free(rag_index* h) {
+    IvfState& v = h->ivf;
+    if (v.quantizer) rag_index_free(v.quantizer);
+    if (v.list_begin_dev) (void)hipFree(v.list_begin_dev);
+    if (v.orig_dev) (void)hipFree(v.orig_dev);
+    v.ws.release();
+    v = IvfState();
+}
+
+// list of every new row = argmax inner product over the centroids (ties: lower list)
+int ivf_assign_new_rows(rag_index* h, long long first, long long count) {
+    IvfState& v = h->ivf;
+    if (!v.quantizer) return fail(RAG_ERR_INVALID, "IVF index is not trained");
+    v.assign.resize((size_t)(first + count));
+    const long long chunk = 65536;
+    std::vector<long long> host_i((size_t)std::min(chunk, count));
+    for (long long c0 = 0; c0 < count; c0 += chunk) {
+        const long long c = std::min(chunk, count - c0);
+        const size_t db = ((size_t)c * sizeof(float) + 255) & ~(size_t)255;
+        if (int rc = v.ws.ensure(db + (size_t)c * sizeof(long long))) return rc;
+        float* D = static_cast<float*>(v.ws.ptr);
+        long long* I = reinterpret_cast<long long*>(static_cast<char*>(v.ws.ptr) + db);
+        // new rows sit at the tail of X in arrival order, already padded to ld
+        const float* rows = h->X + (size_t)(first + c0) * h->ld;
+        if (int rc = flat_search_prepared(v.quantizer, c, rows, 1, -FLT_MAX, nullptr, D, I, h->stream)) return rc;
+        RAG_HIP_CHECK(hipMemcpyAsync(host_i.data(), I, (size_t)c * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+        RAG_HIP_CHECK(hipStreamSynchronize(h->stream));
+        for (long long i = 0; i < c; ++i) {
+            const long long l = host_i[(size_t)i];
+            v.assign[(size_t)(first + c0 + i)] = l < 0 ? 0 : (int)l;     // a NaN row scores nowhere: list 0
+        }
+    }
+    return RAG_OK;
+}
+
+// fold the unsorted tail into list order
+static int ivf_repack(rag_index* h) {
+    IvfState& v = h->ivf;
+    const long long n = h->n;
+    if (v.n_packed == n) return RAG_OK;
+    // current layout: storage position p holds insertion row orig[p]; tail rows are their own position
+    v.orig.resize((size_t)n);
+    v.pos.resize((size_t)n);
+    for (long long p = v.n_packed; p < n; ++p) { v.orig[(size_t)p] = p; v.pos[(size_t)p] = p; }
+    // counting sort of insertion rows by list, stable in insertion order
+    std::vector<long long> begin((size_t)v.nlist + 1, 0);
+    for (long long o = 0; o < n; ++o) begin[(size_t)v.assign[(size_t)o] + 1]++;
+    for (int l = 0; l < v.nlist; ++l) begin[(size_t)l + 1] += begin[(size_t)l];
+    std::vector<long long> cursor(begin.begin(), begin.end() - 1);
+    std::vector<long long> new_orig((size_t)n), src((size_t)n);
+    for (long long o = 0; o < n; ++o) {
+        const long long p = cursor[(size_t)v.assign[(size_t)o]]++;
+        new_orig[(size_t)p] = o;
+        src[(size_t)p] = v.pos[(size_t)o];
+    }
+    // device: gather rows into a fresh buffer in the new order
+    float* nx = nullptr;
+    RAG_HIP_CHECK(hipMalloc((void**)&nx, (size_t)std::max(h->cap, n) * h->ld * sizeof(float)));
+    if (int rc = v.ws.ensure((size_t)n * sizeof(long long))) { (void)hipFree(nx); return rc; }
+    RAG_HIP_CHECK(hipMemcpyAsync(v.ws.ptr, src.data(), (size_t)n * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+    long long blocks = (n + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(gather_packed_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, h->X,
+                       static_cast<const long long*>(v.ws.ptr), n, h->ld / 4, nx);
+    RAG_HIP_CHECK(hipGetLastError());
+    RAG_HIP_CHECK(hipStreamSynchronize(h->stream));
+    (void)hipFree(h->X);
+    h->X = nx;
+    h->cap = std::max(h->cap, n);
+    v.orig.swap(new_orig);
+    for (long long p = 0; p < n; ++p) v.pos[(size_t)v.orig[(size_t)p]] = p;
+    if (v.orig_cap < n) {
+        if (v.orig_dev) (void)hipFree(v.orig_dev);
+        v.orig_cap = std::max(n, v.orig_cap + v.orig_cap / 2);
+        RAG_HIP_CHECK(hipMalloc((void**)&v.orig_dev, (size_t)v.orig_cap * sizeof(long long)));
+    }
+    RAG_HIP_CHECK(hipMemcpy(v.orig_dev, v.orig.data(), (size_t)n * sizeof(long long), hipMemcpyHostToDevice));
+    RAG_HIP_CHECK(hipMemcpy(v.list_begin_dev, begin.data(), ((size_t)v.nlist + 1) * sizeof(long long), hipMemcpyHostToDevice));
+    v.n_packed = n;
+    return RAG_OK;
+}
+
+int ivf_reconstruct_rows(rag_index* h, long long n, const int64_t* rows, std::vector<long long>& storage_rows) {
+    IvfState& v = h->ivf;
+    storage_rows.resize((size_t)n);
+    for (long long i = 0; i < n; ++i) {
+        const long long o = rows[i];
+        storage_rows[(size_t)i] = o < v.n_packed ? v.pos[(size_t)o] : o;   // tail rows are still in arrival order
+    }
+    return RAG_OK;
+}
+
+int ivf_search_device(rag_index* h, long long nq, const float* qbuf, int k, float min_score, int nprobe,
+                      const uint8_t* mask, float* D, long long* I, hipStream_t s) {
+    IvfState& v = h->ivf;
+    if (!v.quantizer) return fail(RAG_ERR_INVALID, "IVF index is not trained");
+    if (nprobe < 1) return fail(RAG_ERR_INVALID, "nprobe must be >= 1");
+    if (nprobe > v.nlist) nprobe = v.nlist;
+    if (nprobe > 1024) return fail(RAG_ERR_INVALID, "nprobe must be <= 1024");
+    if (v.n_packed != h->n) {
+        RAG_HIP_CHECK(hipStreamSynchronize(s));
+        if (int rc = ivf_repack(h)) return rc;
+    }
+    const long long n = h->n;
+    // --- coarse: the nprobe best lists of every query --------------------------------------
+    const size_t cdb = ((size_t)nq * nprobe * sizeof(float) + 255) & ~(size_t)255;
+    const size_t cib = ((size_t)nq * nprobe * sizeof(long long) + 255) & ~(size_t)255;
+    const size_t mb = mask ? (((size_t)n + 255) & ~(size_t)255) : 0;
+    if (int rc = v.ws.ensure(cdb + cib + mb)) return rc;
+    float* cD = static_cast<float*>(v.ws.ptr);
+    long long* cI = reinterpret_cast<long long*>(static_cast<char*>(v.ws.ptr) + cdb);
+    uint8_t* pmask = mask ? reinterpret_cast<uint8_t*>(static_cast<char*>(v.ws.ptr) + cdb + cib) : nullptr;
+    if (int rc = flat_search_prepared(v.quantizer, nq, qbuf, nprobe, -FLT_MAX, nullptr, cD, cI, s)) return rc;
+    if (mask) {
+        long long mblocks = (n + 255) / 256;
+        if (mblocks > 4096) mblocks = 4096;
+        hipLaunchKernelGGL(gather_mask_kernel, dim3((unsigned)mblocks), dim3(256), 0, s, mask, v.orig_dev, n, pmask);
+        RAG_HIP_CHECK(hipGetLastError());
+    }
+    // --- list scan ------------------------------------------------------------------------------
+    const long long slices = ivf_slices(h, nq, nprobe);
+    const int gx = (int)(nprobe * slices);
+    const int waves = gx * 4;
+    const size_t qbytes = ((size_t)nq * h->ld * sizeof(float) + 255) & ~(size_t)255;
+    const long long qchunk = IVF_QCHUNK;
+    if (h->ws.bytes < qbytes + ivf_search_workspace(h, nq, k, nprobe))
+        return fail(RAG_ERR_INVALID, "internal: workspace not sized for the IVF scan");
+    u64* part = reinterpret_cast<u64*>(static_cast<char*>(h->ws.ptr) + qbytes);
+    for (long long q0 = 0; q0 < nq; q0 += qchunk) {
+        const long long qc = std::min(qchunk, nq - q0);
+        ScanArgs a;
+        a.X = h->X;
+        a.Q = qbuf + (size_t)q0 * h->ld;
+        a.mask = pmask;
+        a.part = part;
+        a.n = n;
+        a.d4 = h->ld / 4;
+        a.nch = 0;
+        a.k = k;
+        a.capw = 0;
+        a.nt = 1;
+        a.ivf_lists = cI + (size_t)q0 * nprobe;
+        a.list_begin = v.list_begin_dev;
+        a.row_alias = v.orig_dev;
+        a.ivf_nprobe = nprobe;
+        a.ivf_slices = (int)slices;
+        a.grid_y = (int)qc;
+        if (int rc = profile_begin(h, s)) return rc;
+        RAG_HIP_CHECK(launch_flat_scan(a, 1, gx, s));
+        if (int rc = profile_end(h, s)) return rc;
+        MergeArgs m;
+        m.keys = part;
+        m.per_query = (long long)waves * k;
+        m.k = k;
+        m.cap = std::max(2048, 2 * pow2_ceil(k));
+        m.min_score = min_score;
+        m.row_ids = h->ids_dev;
+        m.id_base = h->id_base;
+        m.slot_ids = nullptr;
+        m.slot_stride = 0;
+        m.D = D + (size_t)q0 * k;
+        m.I = I + (size_t)q0 * k;
+        RAG_HIP_CHECK(launch_merge_keys(m, qc, s));
+    }
+    h->last_path = "ivf";
+    return RAG_OK;
+}
+
+}  // namespace rag
+
+using namespace rag;
+
+extern "C" int rag_index_train_ivf(rag_index_t* h, int nlist, const float* centroids, int64_t nsample, const float* sample) {
+    if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
+    if (h->kind != RAG_KIND_IVF) return fail(RAG_ERR_INVALID, "not an IVF index");
+    if (h->n != 0) return fail(RAG_ERR_INVALID, "train before adding rows");
+    if (nlist < 1 || nlist > (1 << 22)) return fail(RAG_ERR_INVALID, "nlist must be in [1, 4194304]");
+    const float* c = centroids;
+    if (!c) {
+        if (!sample || nsample < nlist) return fail(RAG_ERR_INVALID, "need centroids, or a sample of at least nlist rows");
+        c = sample;   // the first nlist sample rows are the centroids
+    }
+    ivf_free(h);
+    IvfState& v = h->ivf;
+    rag_index* qz = nullptr;
+    // centroids are compared as given (never normalised), whatever the index metric
+    if (int rc = rag_index_create(h->dim, RAG_METRIC_IP, RAG_KIND_FLAT, h->device, &qz)) return rc;
+    if (int rc = rag_index_add(qz, nlist, c, nullptr)) { rag_index_free(qz); return rc; }
+    v.quantizer = qz;
+    v.nlist = nlist;
+    int prev = 0;
+    RAG_HIP_CHECK(hipGetDevice(&prev));
+    RAG_HIP_CHECK(hipSetDevice(h->device));
+    hipError_t e = hipMalloc((void**)&v.list_begin_dev, ((size_t)nlist + 1) * sizeof(long long));
+    if (e == hipSuccess) e = hipMemset(v.list_begin_dev, 0, ((size_t)nlist + 1) * sizeof(long long));
+    (void)hipSetDevice(prev);
+    if (e != hipSuccess) return fail(RAG_ERR_OOM, std::string("list offsets: ") + hipGetErrorString(e));
+    return RAG_OK;
+}

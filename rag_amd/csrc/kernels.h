@@ -19,6 +19,13 @@ struct ScanArgs {
     int k;
     int capw;              // k > 64: keys per wave-private LDS buffer
     int nt;                // 1: non-temporal row loads
+    // IVF mode (ivf_lists != nullptr): grid = (nprobe * ivf_slices, nq), one query per block row
+    const long long* ivf_lists;   // [nq][ivf_nprobe] probed list numbers (-1 = none)
+    const long long* list_begin;  // [nlist + 1] first storage row of every list
+    const long long* row_alias;   // nullptr or storage position -> position reported in keys
+    int ivf_nprobe;
+    int ivf_slices;
+    int grid_y;
 };
 
 struct MergeArgs {

@@ -1,0 +1,75 @@
+"""IVF (coarse assignment + list scan on the GPU) against the CPU oracle with the
+same centroids.  Tolerance as for the exhaustive search."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-5, 1e-6
+
+
+def _unit(rng, n, d):
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    return x / np.linalg.norm(x, axis=1, keepdims=True)
+
+
+def _cmp(D, I, Dr, Ir):
+    from oracle import flat
+    bad = flat.compare_topk(D, I, Dr, Ir, rtol=RTOL, atol=ATOL)
+    assert bad == [], bad[:5]
+
+
+@pytest.mark.parametrize("n,d,nlist,nprobe,nq,k", [
+    (60_000, 128, 64, 8, 1, 10), (60_000, 128, 64, 8, 40, 10), (30_000, 768, 128, 16, 3, 10),
+    (20_000, 384, 32, 32, 5, 100), (5_000, 100, 16, 4, 2, 10), (80_000, 64, 256, 64, 200, 5)])
+def test_ivf_matches_oracle(n, d, nlist, nprobe, nq, k):
+    from oracle import ivf
+    from rag_amd import DeviceIndex
+    rng = np.random.default_rng(n + nlist + nq)
+    X = _unit(rng, n, d)
+    Q = _unit(rng, nq, d)
+    C = X[rng.choice(n, nlist, replace=False)].copy()
+    idx = DeviceIndex(d, metric="ip", kind="ivf")
+    idx.train_ivf(nlist, centroids=C)
+    idx.add(X[: n // 3])
+    D0, I0 = idx.search(Q, k, nprobe=nprobe)                 # search between adds forces a re-pack
+    _cmp(D0, I0, *ivf.ivf_search(X[: n // 3], C, Q, k, nprobe))
+    idx.add(X[n // 3:])
+    D, I = idx.search(Q, k, nprobe=nprobe)
+    assert idx.last_path == "ivf"
+    _cmp(D, I, *ivf.ivf_search(X, C, Q, k, nprobe))
+    # nprobe = nlist degenerates to the exhaustive answer
+    from oracle import flat
+    D, I = idx.search(Q, k, nprobe=nlist)
+    _cmp(D, I, *flat.flat_ip_search(X, Q, k))
+    idx.close()
+
+
+def test_ivf_mask_ids_reconstruct_soft_delete():
+    from oracle import ivf
+    from rag_amd import DeviceIndex, RagHipError
+    rng = np.random.default_rng(4)
+    n, d, nlist = 20_000, 256, 50
+    X = _unit(rng, n, d)
+    Q = _unit(rng, 6, d)
+    C = X[:nlist].copy()
+    ids = rng.permutation(5 * n)[:n].astype(np.int64)
+    idx = DeviceIndex(d, metric="ip", kind="ivf")
+    with pytest.raises(RagHipError):
+        idx.add(X)                                   # untrained
+    idx.train_ivf(nlist, sample=X)                   # first nlist sample rows become the centroids
+    idx.add(X, ids=ids)
+    D, I = idx.search(Q, 10, nprobe=7)
+    _cmp(D, I, *ivf.ivf_search(X, C, Q, 10, 7, ids=ids))
+    mask = (rng.uniform(size=n) < 0.4).astype(np.uint8)
+    D, I = idx.search(Q, 10, nprobe=7, row_mask=mask, min_score=0.02)
+    _cmp(D, I, *ivf.ivf_search(X, C, Q, 10, 7, ids=ids, row_mask=mask, min_score=0.02))
+    R = idx.reconstruct([0, 123, n - 1])
+    assert np.array_equal(R, X[[0, 123, n - 1]])
+    gone = np.arange(0, n, 3)
+    idx.set_active(gone, False)
+    m2 = np.ones(n, np.uint8)
+    m2[gone] = 0
+    D, I = idx.search(Q, 10, nprobe=7)
+    _cmp(D, I, *ivf.ivf_search(X, C, Q, 10, 7, ids=ids, row_mask=m2))
+    idx.close()
