@@ -45,6 +45,20 @@ def parse():
     return ap.parse_args()
 
 
+def measured_traffic(kernel, rows, dim, world):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled as gfx950
+    needs).  Only valid for the shape it was taken on; otherwise None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)
+        if world == 1 and t.get("rows") == rows and t.get("dim") == dim and kernel in t:
+            return t[kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def make_corpus(torch, lo, hi, dim, device, chunk=500_000):
     """Rows [lo, hi) of the global corpus: N(0,1), L2-normalised, fp32.  Chunk c of
     the GLOBAL row space is drawn from seed 1234 + c, so the corpus is the same
@@ -179,7 +193,8 @@ def main():
     k_avg_ms = kms / max(launches, 1)
     achieved_gbs = (hi - lo) * bytes_per_row / (k_avg_ms * 1e-3) / 1e9 if launches else 0.0
     roof1 = {"bound": "hbm", "kernel": "flat_scan_kernel", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
-             "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+             "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
+             "traffic": measured_traffic("flat_scan_kernel", args.rows, args.dim, world),
              "kernel_ms": k_avg_ms, "launches": launches,
              "algorithmic_bytes_per_launch": (hi - lo) * bytes_per_row}
 
@@ -205,7 +220,9 @@ def main():
                "ms_per_step": dtb / nbig * 1e3, "path": pathb,
                "roofline": {"bound": "mfma" if pathb == "gemm" else "hbm", "achieved": ach_tf,
                             "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": ach_tf / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                            "frac": ach_tf / FP32_MFMA_PEAK_TFLOPS,
+                            "traffic": measured_traffic("gemm_topk_kernel", args.rows, args.dim, world)
+                            if B == 4096 else None,
                             "kernel_ms_per_step": kb_ms, "launches": launchesb,
                             "algorithmic_flops_per_step": flops}}
     index.profile(False)
