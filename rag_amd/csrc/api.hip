@@ -165,7 +165,7 @@ static int env_int(const char* name, int dflt) {
 
 // blocks for the scan: enough waves to fill the chip, not more lists than rows justify
 static int scan_blocks(const rag_index* h) {
-    static const int max_blocks = env_int("RAG_SCAN_BLOCKS", 1024);
+    static const int max_blocks = env_int("RAG_SCAN_BLOCKS", 512);
     const int tile = scan_rows_per_tile(h->ld / 4);
     const long long ntiles = (h->n + tile - 1) / tile;
     // at least ~64 tiles per wave before adding another wave; at most 4 blocks per CU

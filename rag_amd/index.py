@@ -142,6 +142,29 @@ class DeviceIndex:
         check(lib.rag_index_train_ivf(self._h, int(nlist), _ptr(c), ns, _ptr(s)))
 
     # -------------------------------------------------------------------- search
+    def search_into(self, q, k: int, d_ptr: int, i_ptr: int, min_score: Optional[float] = None,
+                    nprobe: int = 1, row_mask=None) -> None:
+        """Device search of CUDA-tensor queries with the results written to caller
+        memory: nq*k fp32 scores at d_ptr and nq*k int64 ids at i_ptr (device
+        addresses), enqueued on torch's current stream."""
+        import torch
+        if q.dim() == 1:
+            q = q[None, :]
+        if not _is_torch_cuda(q) or q.dtype != torch.float32 or q.shape[1] != self.dim:
+            raise ValueError(f"expected a CUDA float32 [nq, {self.dim}] tensor")
+        if not 1 <= int(k) <= MAX_K:
+            raise ValueError(f"k must be in [1, {MAX_K}]")
+        q = q.contiguous()
+        m_ptr = None
+        if row_mask is not None:
+            if not _is_torch_cuda(row_mask) or row_mask.dtype != torch.uint8 or row_mask.numel() != len(self):
+                raise ValueError("row_mask must be a CUDA uint8 tensor with one byte per row")
+            m_ptr = C.c_void_p(row_mask.contiguous().data_ptr())
+        ms = -FLT_MAX if min_score is None else float(min_score)
+        stream = torch.cuda.current_stream(q.device).cuda_stream
+        check(lib.rag_index_search_device(self._h, q.shape[0], C.c_void_p(q.data_ptr()), int(k), ms, int(nprobe),
+                                          m_ptr, C.c_void_p(d_ptr), C.c_void_p(i_ptr), C.c_void_p(stream)))
+
     def search(self, q, k: int, min_score: Optional[float] = None, nprobe: int = 1,
                row_mask=None) -> Tuple[object, object]:
         """Returns (D [nq,k] float32, I [nq,k] int64), numpy for numpy queries and
@@ -188,6 +211,19 @@ class DeviceIndex:
                 raise ValueError("row_mask must have one byte per row")
         check(lib.rag_index_search(self._h, nq, _ptr(q), k, ms, int(nprobe), _ptr(m), _ptr(D), _ptr(I)))
         return D, I
+
+
+def merge_topk_strided(nlists: int, nq: int, k: int, d_ptr: int, d_stride: int, i_ptr: int, i_stride: int, device):
+    """Merge `nlists` result sets that sit at d_ptr + g*d_stride floats / i_ptr +
+    g*i_stride int64s in device memory (e.g. the slots of an all-gather buffer)."""
+    import torch
+    Do = torch.empty((nq, k), dtype=torch.float32, device=device)
+    Io = torch.empty((nq, k), dtype=torch.int64, device=device)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    check(lib.rag_merge_topk_device(nlists, nq, k, C.c_void_p(d_ptr), d_stride, C.c_void_p(i_ptr), i_stride,
+                                    C.c_void_p(Do.data_ptr()), C.c_void_p(Io.data_ptr()), device.index,
+                                    C.c_void_p(stream)))
+    return Do, Io
 
 
 def merge_topk(D, I, device: Optional[int] = None):

@@ -52,8 +52,35 @@ class ShardedIndex:
         self._merge = merge
         self._gather_buf = None
 
+    def _search_device(self, q, k: int, **kw):
+        """CUDA-tensor queries on a DeviceIndex: the local search writes straight
+        into this rank's slot of the gather buffer (in-place all-gather), and the
+        merge reads the gathered slots through list strides -- no packing kernels.
+        Slot layout (int64 words): [nq*k ids | ceil(nq*k/2) words holding nq*k fp32 scores]."""
+        import torch
+        from .index import merge_topk_strided
+        if q.dim() == 1:
+            q = q[None, :]
+        nq = q.shape[0]
+        nk = nq * k
+        slot = nk + (nk + 1) // 2
+        shape = (self.world, slot)
+        if self._gather_buf is None or self._gather_buf.shape != shape or self._gather_buf.device != q.device:
+            self._gather_buf = torch.empty(shape, dtype=torch.int64, device=q.device)
+        buf = self._gather_buf
+        mine = buf[self.rank]
+        i_ptr = mine.data_ptr()
+        d_ptr = i_ptr + nk * 8
+        self.index.search_into(q, k, d_ptr, i_ptr, **kw)
+        self.dist.all_gather_into_tensor(buf, mine, group=self.group)
+        return merge_topk_strided(self.world, nq, k, buf.data_ptr() + nk * 8, slot * 2, buf.data_ptr(), slot,
+                                  q.device)
+
     def search(self, q, k: int, **kw):
         import torch
+        if (self.world > 1 and self.index is not None and self._search == self.index.search
+                and type(q).__module__.startswith("torch") and q.is_cuda):
+            return self._search_device(q, k, **kw)
         D, I = self._search(q, k, **kw)
         if self.world == 1:
             return D, I

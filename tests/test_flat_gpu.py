@@ -219,3 +219,35 @@ def test_errors_are_reported():
     with pytest.raises(RagHipError):
         DeviceIndex(16, device=99)
     idx.close()
+
+
+def test_gather_slot_layout_and_strided_merge():
+    """What ShardedIndex does per step on N GPUs, replayed on one: every shard
+    writes (ids | scores) into its slot of the gather buffer, the merge reads the
+    slots through list strides."""
+    import torch
+    from rag_amd import DeviceIndex
+    from rag_amd.index import merge_topk_strided
+    rng = np.random.default_rng(31)
+    n, d, G, k = 30_011, 768, 3, 10
+    X = _unit(rng, n, d)
+    for nq in (1, 5):
+        Q = _unit(rng, nq, d)
+        qt = torch.from_numpy(Q).cuda()
+        nk = nq * k
+        slot = nk + (nk + 1) // 2
+        buf = torch.empty((G, slot), dtype=torch.int64, device="cuda")
+        shards = []
+        for g in range(G):
+            from rag_amd.sharded import shard_range
+            lo, hi = shard_range(n, g, G)
+            sh = DeviceIndex(d, metric="ip")
+            sh.set_id_base(lo)
+            sh.add(X[lo:hi])
+            sh.search_into(qt, k, buf[g].data_ptr() + nk * 8, buf[g].data_ptr())
+            shards.append(sh)
+        Dm, Im = merge_topk_strided(G, nq, k, buf.data_ptr() + nk * 8, slot * 2, buf.data_ptr(), slot, qt.device)
+        torch.cuda.synchronize()
+        _check(Dm.cpu().numpy(), Im.cpu().numpy(), X, Q, k)
+        for sh in shards:
+            sh.close()
