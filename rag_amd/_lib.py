@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librag_hip.so")
+# RAG_HIP_LIB points measurements at an alternative build of the same library (A/B runs)
+LIB_PATH = os.environ.get("RAG_HIP_LIB") or os.path.join(_HERE, "librag_hip.so")
 
 
 class RagHipError(RuntimeError):

@@ -44,6 +44,13 @@ constexpr int GLD = GK + 4;      // padded LDS row stride (floats)
 constexpr int CAPQ = 256;        // candidate keys per query per workgroup
 constexpr int GEMM_MAX_K = 64;
 
+// Timing-only ablations for diagnostic builds (outputs are wrong when non-zero):
+// bit 0 skip the tile epilogue, bit 1 load global tiles only once, bit 2 stage LDS only twice.
+#ifndef RAG_GEMM_DIAG
+#define RAG_GEMM_DIAG 0
+#endif
+constexpr int DIAG = RAG_GEMM_DIAG;
+
 struct GemmArgs {
     const float* X;
     const float* Q;
@@ -59,6 +66,16 @@ struct GemmArgs {
     int nqb_pad;     // query blocks rounded up for the XCD-friendly decode
     int S;           // row ranges
 };
+
+// rare path of the tile epilogue, kept out of line so that the 64 call sites stay small
+__device__ __attribute__((noinline)) void push_candidate(const GemmArgs& a, u64* cand, int* s_cnt, int* s_flag, int ql,
+                                                         long long row, float sc) {
+    if (row < a.n && (!a.mask || a.mask[row])) {
+        const int pos = atomicAdd(&s_cnt[ql], 1);
+        cand[(size_t)ql * CAPQ + pos] = make_key(sc, (uint32_t)row);
+        if (pos + 1 > CAPQ - GT) *s_flag = 1;       // compact before the next tile can overflow it
+    }
+}
 
 __global__ __launch_bounds__(256, 2) void gemm_topk_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -95,125 +112,152 @@ __global__ __launch_bounds__(256, 2) void gemm_topk_kernel(GemmArgs a) {
     const f4* X4 = reinterpret_cast<const f4*>(a.X);
     const f4* Q4 = reinterpret_cast<const f4*>(a.Q);
     const int ld4 = a.ld / 4;
-    int lrow[4], lc4;
-    lc4 = tid & 7;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) lrow[i] = (tid >> 3) + 32 * i;
-    long long qoff[4];
+    const int lc4 = tid & 7;
+    const int lrow0 = tid >> 3;                         // rows lrow0 + 32*i, i = 0..3
+    const f4* qp[4];                                    // this thread's query chunks, k step 0
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        int qr = q0 + lrow[i];
+        int qr = q0 + lrow0 + 32 * i;
         qr = qr < a.nq ? qr : a.nq - 1;
-        qoff[i] = (long long)qr * ld4 + lc4;
+        qp[i] = Q4 + (long long)qr * ld4 + lc4;
     }
-    f4 xr[4], qr4[4];
-    const long long total_steps = (t_end - t_begin) * KT;
-
-    auto issue_load = [&](long long step) {
-        const long long t = t_begin + step / KT;
-        const int kt = (int)(step % KT);
-        const long long n0 = t * GT;
+    const f4* xp[4];                                    // this thread's corpus chunks of the tile being loaded
+    auto set_tile = [&](long long t) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            long long r = n0 + lrow[i];
+            long long r = t * GT + lrow0 + 32 * i;
             r = r < a.n ? r : a.n - 1;
-            xr[i] = X4[r * ld4 + kt * (GK / 4) + lc4];
-            qr4[i] = Q4[qoff[i] + kt * (GK / 4)];
+            xp[i] = X4 + r * ld4 + lc4;
         }
     };
-    auto store_lds = [&](int buf) {
-        float* Ab = As + buf * GT * GLD;
-        float* Bb = Bs + buf * GT * GLD;
+    f4 xr[4], qr4[4];
+    auto issue_load = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f4*>(Ab + lrow[i] * GLD + lc4 * 4) = xr[i];
-            *reinterpret_cast<f4*>(Bb + lrow[i] * GLD + lc4 * 4) = qr4[i];
+            xr[i] = xp[i][kt * (GK / 4)];
+            qr4[i] = qp[i][kt * (GK / 4)];
+        }
+    };
+    const int lds_w = lrow0 * GLD + lc4 * 4;            // float offset of this thread's first staged chunk
+    auto store_lds = [&](int buf) {
+        float* Ab = As + buf * GT * GLD + lds_w;
+        float* Bb = Bs + buf * GT * GLD + lds_w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f4*>(Ab + i * 32 * GLD) = xr[i];
+            *reinterpret_cast<f4*>(Bb + i * 32 * GLD) = qr4[i];
+        }
+    };
+    // one wave sorts the candidate buffer of every query that could overflow on the next
+    // tile; `scratch_buf` is the LDS stage buffer nobody reads or writes right now
+    auto compact = [&](int scratch_buf) {
+        u64* scratch = reinterpret_cast<u64*>(As + scratch_buf * GT * GLD) + wave * CAPQ;
+        for (int ql = wave; ql < GT; ql += 4) {
+            const int c = s_cnt[ql];
+            if (c <= CAPQ - GT) continue;            // wave-uniform
+            for (int i = lane; i < CAPQ; i += 64) scratch[i] = (i < c) ? cand[(size_t)ql * CAPQ + i] : KEY_EMPTY;
+            bitonic_sort_desc_lds(scratch, CAPQ, lane, 64, SyncWave());
+            for (int i = lane; i < k; i += 64) cand[(size_t)ql * CAPQ + i] = scratch[i];
+            if (lane == 0) {
+                s_cnt[ql] = c < k ? c : k;
+                if (c >= k) s_thr[ql] = key_score(scratch[k - 1]);
+            }
+            SyncWave()();
         }
     };
 
     f16v acc[2][2];
-    if (total_steps > 0) issue_load(0);
-    for (long long step = 0; step < total_steps; ++step) {
-        const int kt = (int)(step % KT);
-        const int buf = (int)(step & 1);
-        store_lds(buf);
-        __syncthreads();
-        if (step + 1 < total_steps) issue_load(step + 1);
-        if (kt == 0) {
+    int buf = 0;
+    if (t_begin < t_end) { set_tile(t_begin); issue_load(0); }
+    for (long long t = t_begin; t < t_end; ++t) {
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int nj = 0; nj < 2; ++nj)
+            for (int nj = 0; nj < 2; ++nj)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mi][nj][r] = 0.f;
-        }
-        const float* Ab = As + buf * GT * GLD + (wm * 64 + l31) * GLD + h * 4;
-        const float* Bb = Bs + buf * GT * GLD + (wq * 64 + l31) * GLD + h * 4;
+                for (int r = 0; r < 16; ++r) acc[mi][nj][r] = 0.f;
+        for (int kt = 0; kt < KT; ++kt, buf ^= 1) {
+            if (!(DIAG & 4) || (t == t_begin && kt < 2)) {
+                store_lds(buf);
+                __syncthreads();
+            }
+            // a candidate buffer filled up during the previous tile's epilogue: every wave has
+            // passed the barrier above, so the flag is stable and buffer buf^1 is idle
+            if (kt == 0 && *s_flag != 0) {
+                compact(buf ^ 1);
+                __syncthreads();
+                if (tid == 0) *s_flag = 0;
+            }
+            if (!(DIAG & 2) || (t == t_begin && kt == 0)) {
+                if (kt + 1 < KT) issue_load(kt + 1);
+                else if (t + 1 < t_end) { set_tile(t + 1); issue_load(0); }
+            }
+            const float* Ab = As + buf * GT * GLD + (wm * 64 + l31) * GLD + h * 4;
+            const float* Bb = Bs + buf * GT * GLD + (wq * 64 + l31) * GLD + h * 4;
+            // fragments of k block kb+1 are requested before the MFMAs of block kb issue
+            f4 fa0 = *reinterpret_cast<const f4*>(Ab);
+            f4 fa1 = *reinterpret_cast<const f4*>(Ab + 32 * GLD);
+            f4 fb0 = *reinterpret_cast<const f4*>(Bb);
+            f4 fb1 = *reinterpret_cast<const f4*>(Bb + 32 * GLD);
 #pragma unroll
-        for (int kb = 0; kb < GK / 8; ++kb) {
-            const f4 a0 = *reinterpret_cast<const f4*>(Ab + kb * 8);
-            const f4 a1 = *reinterpret_cast<const f4*>(Ab + 32 * GLD + kb * 8);
-            const f4 b0 = *reinterpret_cast<const f4*>(Bb + kb * 8);
-            const f4 b1 = *reinterpret_cast<const f4*>(Bb + 32 * GLD + kb * 8);
+            for (int kb = 0; kb < GK / 8; ++kb) {
+                const f4 a0 = fa0, a1 = fa1, b0 = fb0, b1 = fb1;
+                if (kb + 1 < GK / 8) {
+                    fa0 = *reinterpret_cast<const f4*>(Ab + (kb + 1) * 8);
+                    fa1 = *reinterpret_cast<const f4*>(Ab + 32 * GLD + (kb + 1) * 8);
+                    fb0 = *reinterpret_cast<const f4*>(Bb + (kb + 1) * 8);
+                    fb1 = *reinterpret_cast<const f4*>(Bb + 32 * GLD + (kb + 1) * 8);
+                }
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b1[s], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b0[s], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc[1][1], 0, 0, 0);
+                for (int s = 0; s < 4; ++s) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b1[s], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b0[s], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc[1][1], 0, 0, 0);
+                }
             }
         }
-        if (kt != KT - 1) continue;
+        if (DIAG & 1) {
+            float keep = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) keep += acc[0][0][r] + acc[0][1][r] + acc[1][0][r] + acc[1][1][r];
+            if (keep == 123.456f) s_thr[0] = keep;      // keeps the accumulators live
+            continue;
+        }
 
-        // ---- tile epilogue: threshold test, rare pushes ----------------------------
-        const long long n0 = (t_begin + step / KT) * GT;
+        // ---- tile epilogue.  A lane owns two queries and 32 scores of each.  First the
+        // cheap test "does any of my scores beat its query's threshold" (a max tree and one
+        // ballot); only a wave with a hit walks its accumulators.
+        const long long n0 = t * GT;
+        float thr[2];
+        bool hit = false;
 #pragma unroll
         for (int nj = 0; nj < 2; ++nj) {
             const int ql = wq * 64 + nj * 32 + l31;
-            const bool qok = (q0 + ql) < a.nq;
-            const float thr = qok ? s_thr[ql] : INFINITY;
+            thr[nj] = (q0 + ql) < a.nq ? s_thr[ql] : INFINITY;
+            float m = -INFINITY;
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
+            for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float sc = acc[mi][nj][r];
-                    if (sc > thr) {
-                        const long long row = n0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        if (row < a.n && (!a.mask || a.mask[row])) {
-                            const int pos = atomicAdd(&s_cnt[ql], 1);
-                            cand[(size_t)ql * CAPQ + pos] = make_key(sc, (uint32_t)row);
-                        }
+                for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[mi][nj][r]);
+            hit |= m > thr[nj];
+        }
+        if (__ballot(hit) != 0ull) {
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj) {
+                const int ql = wq * 64 + nj * 32 + l31;
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float sc = acc[mi][nj][r];
+                        if (sc > thr[nj])
+                            push_candidate(a, cand, s_cnt, s_flag, ql, n0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, sc);
                     }
                 }
             }
         }
-        __syncthreads();
-        // ---- compaction of the queries whose buffer could overflow on the next tile --
-        bool any = false;
-        for (int i = tid; i < GT; i += 256) any |= s_cnt[i] > CAPQ - GT;
-        if (any) *s_flag = 1;
-        __syncthreads();
-        const bool need = *s_flag != 0;
-        if (need) {
-            u64* scratch = reinterpret_cast<u64*>(As + (buf ^ 1) * GT * GLD) + wave * CAPQ;
-            for (int ql = wave; ql < GT; ql += 4) {
-                const int c = s_cnt[ql];
-                if (c <= CAPQ - GT) continue;            // wave-uniform
-                for (int i = lane; i < CAPQ; i += 64) scratch[i] = (i < c) ? cand[(size_t)ql * CAPQ + i] : KEY_EMPTY;
-                bitonic_sort_desc_lds(scratch, CAPQ, lane, 64, SyncWave());
-                for (int i = lane; i < k; i += 64) cand[(size_t)ql * CAPQ + i] = scratch[i];
-                if (lane == 0) {
-                    s_cnt[ql] = c < k ? c : k;
-                    if (c >= k) s_thr[ql] = key_score(scratch[k - 1]);
-                }
-                SyncWave()();
-            }
-            __syncthreads();
-            if (tid == 0) *s_flag = 0;
-            __syncthreads();
-        }
     }
-
     // ---- final: every query's k best keys of this row range -> part ---------------------
     __syncthreads();
     {

@@ -54,8 +54,8 @@ class ShardedIndex:
 
     def _search_device(self, q, k: int, **kw):
         """CUDA-tensor queries on a DeviceIndex: the local search writes straight
-        into this rank's slot of the gather buffer (in-place all-gather), and the
-        merge reads the gathered slots through list strides -- no packing kernels.
+        into the send buffer of the all-gather, and the merge reads the gathered
+        slots through list strides -- no packing or unpacking kernels.
         Slot layout (int64 words): [nq*k ids | ceil(nq*k/2) words holding nq*k fp32 scores]."""
         import torch
         from .index import merge_topk_strided
@@ -67,8 +67,9 @@ class ShardedIndex:
         shape = (self.world, slot)
         if self._gather_buf is None or self._gather_buf.shape != shape or self._gather_buf.device != q.device:
             self._gather_buf = torch.empty(shape, dtype=torch.int64, device=q.device)
+            self._send_buf = torch.empty((slot,), dtype=torch.int64, device=q.device)
         buf = self._gather_buf
-        mine = buf[self.rank]
+        mine = self._send_buf
         i_ptr = mine.data_ptr()
         d_ptr = i_ptr + nk * 8
         self.index.search_into(q, k, d_ptr, i_ptr, **kw)
