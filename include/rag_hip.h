@@ -100,7 +100,16 @@ int rag_index_search(rag_index_t* h, int64_t nq, const float* q, int k, float mi
 int rag_index_search_device(rag_index_t* h, int64_t nq, const float* q_dev, int k,
                             float min_score, int nprobe, const uint8_t* row_mask_dev,
                             float* D_dev, int64_t* I_dev, void* stream);
-/* which kernel the last search on this index used ("scan", "gemm", "ivf") */
+/* Search restricted to row ranges of a FLAT index ("segments", e.g. the chunks of one
+ * document inside a pooled collection): the k best of every (query, segment) pair in
+ * ONE pass.  Replaces the per-document / per-strategy loops of
+ * vector_db/search_manager.py:879-913 and :998-1015 (one RPC per pair there).
+ *   seg_begin/seg_end  nseg row ranges [begin, end) within [0, ntotal)
+ *   D, I               [nq][nseg][k], same conventions as rag_index_search */
+int rag_index_search_segments(rag_index_t* h, int64_t nq, const float* q, int64_t nseg,
+                              const int64_t* seg_begin, const int64_t* seg_end, int k,
+                              float min_score, const uint8_t* row_mask, float* D, int64_t* I);
+/* which kernel the last search on this index used ("scan", "gemm", "ivf", "segments") */
 const char* rag_index_last_path(const rag_index_t* h);
 
 /* multi-GPU step after the all-gather of per-shard results: merge `nlists`

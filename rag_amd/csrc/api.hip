@@ -163,6 +163,12 @@ static int env_int(const char* name, int dflt) {
     return (v && *v) ? atoi(v) : dflt;
 }
 
+// LDS capacity (keys) of merge_keys_kernel: everything at once when the input is small
+int merge_cap(long long per_query, int k) {
+    if (per_query <= 2048) return std::max(64, pow2_ceil((int)std::max<long long>(per_query, 2 * k)));
+    return std::max(2048, 2 * pow2_ceil(k));
+}
+
 // blocks for the scan: enough waves to fill the chip, not more lists than rows justify
 static int scan_blocks(const rag_index* h) {
     static const int max_blocks = env_int("RAG_SCAN_BLOCKS", 512);
@@ -189,7 +195,7 @@ static int flat_scan_search(rag_index* h, long long nq, const float* qbuf, int k
     // (the caller placed qbuf at ws.ptr; keep it there)
     if (int rc = h->ws.ensure(qbytes + pbytes)) return rc;
     u64* part = reinterpret_cast<u64*>(static_cast<char*>(h->ws.ptr) + qbytes);
-    int cap = std::max(2048, 2 * pow2_ceil(k));
+    const int cap = merge_cap((long long)waves * k, k);
     long long q0 = 0;
     while (q0 < nq) {
         int g = 1;
@@ -197,7 +203,7 @@ static int flat_scan_search(rag_index* h, long long nq, const float* qbuf, int k
             const long long left = nq - q0;
             g = left >= 8 ? 8 : left >= 4 ? 4 : left >= 2 ? 2 : 1;
         }
-        ScanArgs a;
+        ScanArgs a = {};
         a.X = h->X;
         a.Q = qbuf + q0 * h->ld;
         a.mask = mask;
@@ -538,6 +544,105 @@ int rag_index_search(rag_index_t* h, int64_t nq, const float* q, int k, float mi
     return RAG_OK;
 }
 
+int rag_index_search_segments(rag_index_t* h, int64_t nq, const float* q, int64_t nseg, const int64_t* seg_begin,
+                              const int64_t* seg_end, int k, float min_score, const uint8_t* row_mask, float* D,
+                              int64_t* I) {
+    if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
+    if (h->kind != RAG_KIND_FLAT) return fail(RAG_ERR_UNSUPPORTED, "segment search needs a FLAT index");
+    if (nq < 0 || nseg < 0) return fail(RAG_ERR_INVALID, "nq / nseg < 0");
+    if (k < 1 || k > 1024) return fail(RAG_ERR_INVALID, "k must be in [1, 1024]");
+    if (nq == 0 || nseg == 0) return RAG_OK;
+    if (!q || !seg_begin || !seg_end || !D || !I) return fail(RAG_ERR_INVALID, "NULL buffer");
+    if (nq > 65535) return fail(RAG_ERR_INVALID, "at most 65535 queries per segment search");
+    long long rows_total = 0;
+    for (int64_t i = 0; i < nseg; ++i) {
+        if (seg_begin[i] < 0 || seg_end[i] < seg_begin[i] || seg_end[i] > h->n)
+            return fail(RAG_ERR_INVALID, "segment " + std::to_string(i) + " is not a row range of the index");
+        rows_total += seg_end[i] - seg_begin[i];
+    }
+    DeviceGuard g(h->device);
+    hipStream_t s = h->stream;
+    // effective mask
+    const uint8_t* mask = nullptr;
+    const size_t mb = (((size_t)h->n + 255) & ~(size_t)255);
+    const size_t sb = ((size_t)nseg * sizeof(long long) + 255) & ~(size_t)255;
+    const size_t db = ((size_t)nq * nseg * k * sizeof(float) + 255) & ~(size_t)255;
+    const size_t ib = ((size_t)nq * nseg * k * sizeof(long long) + 255) & ~(size_t)255;
+    const size_t qhb = ((size_t)nq * h->dim * sizeof(float) + 255) & ~(size_t)255;
+    if (int rc = h->ws2.ensure(2 * mb + 2 * sb + db + ib + qhb)) return rc;
+    char* base = static_cast<char*>(h->ws2.ptr);
+    uint8_t* m_user = reinterpret_cast<uint8_t*>(base);
+    uint8_t* m_comb = reinterpret_cast<uint8_t*>(base + mb);
+    long long* d_sb = reinterpret_cast<long long*>(base + 2 * mb);
+    long long* d_se = reinterpret_cast<long long*>(base + 2 * mb + sb);
+    float* D_dev = reinterpret_cast<float*>(base + 2 * mb + 2 * sb);
+    long long* I_dev = reinterpret_cast<long long*>(base + 2 * mb + 2 * sb + db);
+    float* q_dev = reinterpret_cast<float*>(base + 2 * mb + 2 * sb + db + ib);
+    if (row_mask) {
+        RAG_HIP_CHECK(hipMemcpyAsync(m_user, row_mask, (size_t)h->n, hipMemcpyHostToDevice, s));
+        mask = m_user;
+    }
+    if (h->active) {
+        if (mask) {
+            hipLaunchKernelGGL(and_masks_kernel, dim3(grid_for(h->n)), dim3(256), 0, s, h->active, mask, h->n, m_comb);
+            RAG_HIP_CHECK(hipGetLastError());
+            mask = m_comb;
+        } else {
+            mask = h->active;
+        }
+    }
+    RAG_HIP_CHECK(hipMemcpyAsync(d_sb, seg_begin, (size_t)nseg * sizeof(long long), hipMemcpyHostToDevice, s));
+    RAG_HIP_CHECK(hipMemcpyAsync(d_se, seg_end, (size_t)nseg * sizeof(long long), hipMemcpyHostToDevice, s));
+    RAG_HIP_CHECK(hipMemcpyAsync(q_dev, q, (size_t)nq * h->dim * sizeof(float), hipMemcpyHostToDevice, s));
+    // slices per segment: more blocks only when segments are long and few
+    const int tile = scan_rows_per_tile(h->ld / 4);
+    const long long avg_tiles = std::max<long long>(1, (rows_total / nseg) / tile);
+    long long slices = 2048 / std::max<long long>(1, nq * nseg);
+    slices = std::min<long long>(slices, std::max<long long>(1, avg_tiles / 32));
+    if (slices < 1) slices = 1;
+    const long long gx = nseg * slices;
+    if (gx > 0x7FFFFFFFLL) return fail(RAG_ERR_INVALID, "too many segments");
+    const int waves = (int)slices * 4;                      // per (query, segment)
+    const size_t qbytes = ((size_t)nq * h->ld * sizeof(float) + 255) & ~(size_t)255;
+    const size_t pbytes = (size_t)nq * nseg * waves * k * sizeof(u64);
+    if (int rc = h->ws.ensure(qbytes + pbytes)) return rc;
+    float* qbuf = static_cast<float*>(h->ws.ptr);
+    u64* part = reinterpret_cast<u64*>(static_cast<char*>(h->ws.ptr) + qbytes);
+    RAG_HIP_CHECK(launch_prep_queries(q_dev, nq, h->dim, h->ld, h->metric == RAG_METRIC_COSINE, qbuf, s));
+    ScanArgs a = {};
+    a.X = h->X;
+    a.Q = qbuf;
+    a.mask = mask;
+    a.part = part;
+    a.n = h->n;
+    a.d4 = h->ld / 4;
+    a.k = k;
+    a.nt = 0;
+    a.seg_begin = d_sb;
+    a.seg_end = d_se;
+    a.ivf_slices = (int)slices;
+    a.grid_y = (int)nq;
+    if (int rc = profile_begin(h, s)) return rc;
+    RAG_HIP_CHECK(launch_flat_scan(a, 1, (int)gx, s));
+    if (int rc = profile_end(h, s)) return rc;
+    MergeArgs m = {};
+    m.keys = part;
+    m.per_query = (long long)waves * k;
+    m.k = k;
+    m.cap = merge_cap(m.per_query, k);
+    m.min_score = min_score;
+    m.row_ids = h->ids_dev;
+    m.id_base = h->id_base;
+    m.D = D_dev;
+    m.I = I_dev;
+    RAG_HIP_CHECK(launch_merge_keys(m, nq * nseg, s));
+    RAG_HIP_CHECK(hipMemcpyAsync(D, D_dev, (size_t)nq * nseg * k * sizeof(float), hipMemcpyDeviceToHost, s));
+    RAG_HIP_CHECK(hipMemcpyAsync(I, I_dev, (size_t)nq * nseg * k * sizeof(long long), hipMemcpyDeviceToHost, s));
+    RAG_HIP_CHECK(hipStreamSynchronize(s));
+    h->last_path = "segments";
+    return RAG_OK;
+}
+
 int rag_merge_topk_device(int nlists, int64_t nq, int k, const float* D_dev, int64_t d_list_stride, const int64_t* I_dev,
                           int64_t i_list_stride, float* D_out_dev, int64_t* I_out_dev, int device, void* stream) {
     if (d_list_stride == 0) d_list_stride = nq * k;
@@ -559,7 +664,7 @@ int rag_merge_topk_device(int nlists, int64_t nq, int k, const float* D_dev, int
     m.keys = keys;
     m.per_query = (long long)nlists * k;
     m.k = k;
-    m.cap = std::max(2048, 2 * pow2_ceil(k));
+    m.cap = merge_cap(m.per_query, k);
     m.min_score = -FLT_MAX;
     m.row_ids = nullptr;
     m.id_base = 0;

@@ -74,11 +74,16 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(ScanArgs a) {
     //   IVF: blockIdx.y = query, blockIdx.x = (probed list, slice of the list); the
     //        block's four waves share the slice
     long long r_begin = 0, r_end = a.n, t0 = w, tstride = nwaves;
-    if (a.ivf_lists) {
+    if (a.ivf_lists || a.seg_begin) {
         const int probe = blockIdx.x / a.ivf_slices, slice = blockIdx.x % a.ivf_slices;
-        const long long lst = a.ivf_lists[(size_t)blockIdx.y * a.ivf_nprobe + probe];
         long long lb = 0, le = 0;
-        if (lst >= 0) { lb = a.list_begin[lst]; le = a.list_begin[lst + 1]; }
+        if (a.seg_begin) {
+            lb = a.seg_begin[probe];
+            le = a.seg_end[probe];
+        } else {
+            const long long lst = a.ivf_lists[(size_t)blockIdx.y * a.ivf_nprobe + probe];
+            if (lst >= 0) { lb = a.list_begin[lst]; le = a.list_begin[lst + 1]; }
+        }
         const long long ltiles = (le - lb + TILE - 1) / TILE;
         r_begin = lb + (ltiles * slice / a.ivf_slices) * TILE;
         const long long e = lb + (ltiles * (slice + 1) / a.ivf_slices) * TILE;
@@ -264,7 +269,8 @@ __global__ __launch_bounds__(1024) void merge_keys_kernel(MergeArgs a) {
     for (long long base = 0; base < a.per_query; base += 1024) {
         const int c = *s_cnt;
         __syncthreads();              // every thread has read the count before anyone appends
-        if (c + 1024 > cap) {
+        const long long left = a.per_query - base;
+        if (c + (left < 1024 ? (int)left : 1024) > cap) {
             bitonic_sort_desc_lds(buf, cap, tid, 1024, SyncBlock());
             const u64 t = buf[k - 1];
             __syncthreads();
@@ -377,7 +383,7 @@ static hipError_t launch_scan_t2(const ScanArgs& a, int blocks, size_t lds, hipS
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(blocks, a.ivf_lists ? a.grid_y : 1), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(blocks, (a.ivf_lists || a.seg_begin) ? a.grid_y : 1), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 

@@ -35,6 +35,8 @@
 
 namespace rag {
 
+int merge_cap(long long per_query, int k);
+
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 
@@ -323,7 +325,7 @@ int gemm_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float
     m.keys = a.part;
     m.per_query = (long long)a.S * k;
     m.k = k;
-    m.cap = 2048;
+    m.cap = merge_cap(m.per_query, k);
     m.min_score = min_score;
     m.row_ids = h->ids_dev;
     m.id_base = h->id_base;

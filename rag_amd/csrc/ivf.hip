@@ -26,6 +26,7 @@ namespace rag {
 
 int flat_search_prepared(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask,
                          float* D, long long* I, hipStream_t s);
+int merge_cap(long long per_query, int k);
 
 __global__ void gather_packed_rows_kernel(const float* src, const long long* src_row, long long n, int ld4, float* dst) {
     // one wave per destination row
@@ -196,7 +197,7 @@ int ivf_search_device(rag_index* h, long long nq, const float* qbuf, int k, floa
     u64* part = reinterpret_cast<u64*>(static_cast<char*>(h->ws.ptr) + qbytes);
     for (long long q0 = 0; q0 < nq; q0 += qchunk) {
         const long long qc = std::min(qchunk, nq - q0);
-        ScanArgs a;
+        ScanArgs a = {};
         a.X = h->X;
         a.Q = qbuf + (size_t)q0 * h->ld;
         a.mask = pmask;
@@ -220,7 +221,7 @@ int ivf_search_device(rag_index* h, long long nq, const float* qbuf, int k, floa
         m.keys = part;
         m.per_query = (long long)waves * k;
         m.k = k;
-        m.cap = std::max(2048, 2 * pow2_ceil(k));
+        m.cap = merge_cap(m.per_query, k);
         m.min_score = min_score;
         m.row_ids = h->ids_dev;
         m.id_base = h->id_base;

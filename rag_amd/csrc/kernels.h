@@ -23,6 +23,10 @@ struct ScanArgs {
     const long long* ivf_lists;   // [nq][ivf_nprobe] probed list numbers (-1 = none)
     const long long* list_begin;  // [nlist + 1] first storage row of every list
     const long long* row_alias;   // nullptr or storage position -> position reported in keys
+    // segment mode (seg_begin != nullptr): grid = (nseg * ivf_slices, nq); block row = query,
+    // block column = (segment, slice); rows [seg_begin[s], seg_end[s])
+    const long long* seg_begin;
+    const long long* seg_end;
     int ivf_nprobe;
     int ivf_slices;
     int grid_y;

@@ -165,6 +165,34 @@ class DeviceIndex:
         check(lib.rag_index_search_device(self._h, q.shape[0], C.c_void_p(q.data_ptr()), int(k), ms, int(nprobe),
                                           m_ptr, C.c_void_p(d_ptr), C.c_void_p(i_ptr), C.c_void_p(stream)))
 
+    def search_segments(self, q, segments, k: int, min_score: Optional[float] = None, row_mask=None):
+        """The k best of every (query, row range) pair in one device pass.
+        ``segments``: [(begin, end), ...] row ranges.  Returns numpy (D, I) of shape
+        [nq, nseg, k]."""
+        k = int(k)
+        if not 1 <= k <= MAX_K:
+            raise ValueError(f"k must be in [1, {MAX_K}]")
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        if q.ndim != 2 or q.shape[1] != self.dim:
+            raise ValueError(f"expected float32 [nq, {self.dim}] array, got {q.shape}")
+        seg = np.ascontiguousarray(segments, dtype=np.int64).reshape(-1, 2)
+        sb = np.ascontiguousarray(seg[:, 0])
+        se = np.ascontiguousarray(seg[:, 1])
+        nq, ns = q.shape[0], seg.shape[0]
+        D = np.full((nq, ns, k), -FLT_MAX, dtype=np.float32)
+        I = np.full((nq, ns, k), -1, dtype=np.int64)
+        m = None
+        if row_mask is not None:
+            m = np.ascontiguousarray(row_mask, dtype=np.uint8).reshape(-1)
+            if m.size != len(self):
+                raise ValueError("row_mask must have one byte per row")
+        ms = -FLT_MAX if min_score is None else float(min_score)
+        check(lib.rag_index_search_segments(self._h, nq, _ptr(q), ns, _ptr(sb), _ptr(se), k, ms, _ptr(m),
+                                            _ptr(D), _ptr(I)))
+        return D, I
+
     def search(self, q, k: int, min_score: Optional[float] = None, nprobe: int = 1,
                row_mask=None) -> Tuple[object, object]:
         """Returns (D [nq,k] float32, I [nq,k] int64), numpy for numpy queries and
