@@ -81,6 +81,12 @@ int rag_index_set_active(rag_index_t* h, int64_t n, const int64_t* rows, int act
  * qdrant retrieve(with_vectors): copy rows (by row position) to out[n x dim]. */
 int rag_index_reconstruct(rag_index_t* h, int64_t n, const int64_t* rows, float* out);
 
+/* vector_db/qdrant_client.py:475-621 backup_collection / :623-764 restore_collection:
+ * a binary snapshot of a FLAT index (header, fp32 rows, ids, soft-delete bytes) in
+ * place of the reference's JSON list-of-floats file.  Payloads stay with the caller. */
+int rag_index_save(rag_index_t* h, const char* path);
+int rag_index_load(const char* path, int device, rag_index_t** out);
+
 /* ---- search ---------------------------------------------------------------
  * vector_db/search_optimizer.py:146-274 search (nq = 1) and :276-323
  * batch_search (nq > 1), i.e. the client.search call at :213-222.

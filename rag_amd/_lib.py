@@ -45,6 +45,8 @@ SIGNATURES = {
     "rag_index_dim": (_i32, [_vp]),
     "rag_index_set_active": (_i32, [_vp, _i64, _vp, _i32]),
     "rag_index_reconstruct": (_i32, [_vp, _i64, _vp, _vp]),
+    "rag_index_save": (_i32, [_vp, C.c_char_p]),
+    "rag_index_load": (_i32, [C.c_char_p, _i32, C.POINTER(_vp)]),
     "rag_index_search": (_i32, [_vp, _i64, _vp, _i32, _f32, _i32, _vp, _vp, _vp]),
     "rag_index_search_device": (_i32, [_vp, _i64, _vp, _i32, _f32, _i32, _vp, _vp, _vp, _vp]),
     "rag_index_search_segments": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _f32, _vp, _vp, _vp]),

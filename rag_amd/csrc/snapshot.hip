@@ -1,0 +1,125 @@
+// Binary snapshot of a FLAT index: what the reference's JSON backup of a Qdrant
+// collection (vector_db/qdrant_client.py:475-621, every vector as a list of
+// Python floats) becomes when the vectors live in HBM.
+//
+//   header   magic "RAGHIP01", dim, metric, n, id_base, flags (bit0 ids, bit1 active)
+//   rows     n x dim fp32, row-major, as stored (COSINE rows are normalised)
+//   ids      n x int64            (flag bit 0)
+//   active   n x uint8            (flag bit 1)
+// Payloads stay with the caller (a JSON sidecar written by the Python layer).
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "index.h"
+
+using namespace rag;
+
+namespace {
+struct SnapHeader {
+    char magic[8];
+    int32_t dim;
+    int32_t metric;
+    int64_t n;
+    int64_t id_base;
+    int32_t flags;
+    int32_t reserved;
+};
+const char kMagic[8] = {'R', 'A', 'G', 'H', 'I', 'P', '0', '1'};
+struct FileCloser {
+    FILE* f;
+    ~FileCloser() { if (f) fclose(f); }
+};
+}  // namespace
+
+extern "C" int rag_index_save(rag_index_t* h, const char* path) {
+    if (!h || !path) return fail(RAG_ERR_INVALID, "NULL argument");
+    if (h->kind != RAG_KIND_FLAT) return fail(RAG_ERR_UNSUPPORTED, "snapshots cover FLAT indexes");
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(RAG_ERR_INVALID, std::string("cannot open for writing: ") + path);
+    FileCloser fc{f};
+    int prev = 0;
+    RAG_HIP_CHECK(hipGetDevice(&prev));
+    RAG_HIP_CHECK(hipSetDevice(h->device));
+    struct Restore { int p; ~Restore() { (void)hipSetDevice(p); } } restore{prev};
+    SnapHeader hd;
+    memset(&hd, 0, sizeof(hd));
+    memcpy(hd.magic, kMagic, 8);
+    hd.dim = h->dim;
+    hd.metric = h->metric;
+    hd.n = h->n;
+    hd.id_base = h->id_base;
+    hd.flags = (h->ids_dev ? 1 : 0) | (h->active ? 2 : 0);
+    if (fwrite(&hd, sizeof(hd), 1, f) != 1) return fail(RAG_ERR_INVALID, "write failed");
+    // rows, 64 MiB at a time, padding stripped
+    const long long chunk = std::max<long long>(1, (64LL << 20) / ((long long)h->ld * 4));
+    std::vector<float> host((size_t)std::min<long long>(chunk, std::max<long long>(h->n, 1)) * h->ld);
+    for (long long r0 = 0; r0 < h->n; r0 += chunk) {
+        const long long c = std::min(chunk, h->n - r0);
+        RAG_HIP_CHECK(hipMemcpy(host.data(), h->X + (size_t)r0 * h->ld, (size_t)c * h->ld * sizeof(float), hipMemcpyDeviceToHost));
+        if (h->ld == h->dim) {
+            if (fwrite(host.data(), sizeof(float), (size_t)c * h->dim, f) != (size_t)c * h->dim) return fail(RAG_ERR_INVALID, "write failed");
+        } else {
+            for (long long r = 0; r < c; ++r)
+                if (fwrite(host.data() + (size_t)r * h->ld, sizeof(float), (size_t)h->dim, f) != (size_t)h->dim) return fail(RAG_ERR_INVALID, "write failed");
+        }
+    }
+    if (h->ids_dev && h->n > 0) {
+        std::vector<long long> ids((size_t)h->n);
+        RAG_HIP_CHECK(hipMemcpy(ids.data(), h->ids_dev, (size_t)h->n * sizeof(long long), hipMemcpyDeviceToHost));
+        if (fwrite(ids.data(), sizeof(long long), (size_t)h->n, f) != (size_t)h->n) return fail(RAG_ERR_INVALID, "write failed");
+    }
+    if (h->active && h->n > 0) {
+        std::vector<uint8_t> act((size_t)h->n);
+        RAG_HIP_CHECK(hipMemcpy(act.data(), h->active, (size_t)h->n, hipMemcpyDeviceToHost));
+        if (fwrite(act.data(), 1, (size_t)h->n, f) != (size_t)h->n) return fail(RAG_ERR_INVALID, "write failed");
+    }
+    return RAG_OK;
+}
+
+extern "C" int rag_index_load(const char* path, int device, rag_index_t** out) {
+    if (!path || !out) return fail(RAG_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(RAG_ERR_INVALID, std::string("cannot open: ") + path);
+    FileCloser fc{f};
+    SnapHeader hd;
+    if (fread(&hd, sizeof(hd), 1, f) != 1 || memcmp(hd.magic, kMagic, 8) != 0) return fail(RAG_ERR_INVALID, "not a rag_hip snapshot");
+    if (hd.n < 0 || hd.dim < 1) return fail(RAG_ERR_INVALID, "corrupt snapshot header");
+    rag_index* h = nullptr;
+    // rows in the file are already normalised for COSINE: load them as they are, then restore the metric
+    if (int rc = rag_index_create(hd.dim, RAG_METRIC_IP, RAG_KIND_FLAT, device, &h)) return rc;
+    struct Guard { rag_index* h; bool keep; ~Guard() { if (!keep) rag_index_free(h); } } guard{h, false};
+    if (int rc = rag_index_set_id_base(h, hd.id_base)) return rc;
+    if (int rc = rag_index_reserve(h, hd.n)) return rc;
+    const long long chunk = std::max<long long>(1, (64LL << 20) / ((long long)hd.dim * 4));
+    std::vector<float> host((size_t)std::min<long long>(chunk, std::max<long long>(hd.n, 1)) * hd.dim);
+    for (long long r0 = 0; r0 < hd.n; r0 += chunk) {
+        const long long c = std::min(chunk, hd.n - r0);
+        if (fread(host.data(), sizeof(float), (size_t)c * hd.dim, f) != (size_t)c * hd.dim) return fail(RAG_ERR_INVALID, "truncated snapshot (rows)");
+        if (int rc = rag_index_add(h, c, host.data(), nullptr)) return rc;
+    }
+    h->metric = hd.metric;
+    int prev = 0;
+    RAG_HIP_CHECK(hipGetDevice(&prev));
+    RAG_HIP_CHECK(hipSetDevice(device));
+    struct Restore { int p; ~Restore() { (void)hipSetDevice(p); } } restore{prev};
+    if ((hd.flags & 1) && hd.n > 0) {
+        std::vector<long long> ids((size_t)hd.n);
+        if (fread(ids.data(), sizeof(long long), (size_t)hd.n, f) != (size_t)hd.n) return fail(RAG_ERR_INVALID, "truncated snapshot (ids)");
+        RAG_HIP_CHECK(hipMalloc((void**)&h->ids_dev, (size_t)h->cap * sizeof(long long)));
+        RAG_HIP_CHECK(hipMemcpy(h->ids_dev, ids.data(), (size_t)hd.n * sizeof(long long), hipMemcpyHostToDevice));
+    }
+    if ((hd.flags & 2) && hd.n > 0) {
+        std::vector<uint8_t> act((size_t)hd.n);
+        if (fread(act.data(), 1, (size_t)hd.n, f) != (size_t)hd.n) return fail(RAG_ERR_INVALID, "truncated snapshot (active)");
+        RAG_HIP_CHECK(hipMalloc((void**)&h->active, (size_t)std::max<long long>(h->cap, 1)));
+        RAG_HIP_CHECK(hipMemset(h->active, 1, (size_t)std::max<long long>(h->cap, 1)));
+        RAG_HIP_CHECK(hipMemcpy(h->active, act.data(), (size_t)hd.n, hipMemcpyHostToDevice));
+    }
+    guard.keep = true;
+    *out = h;
+    return RAG_OK;
+}

@@ -9,6 +9,7 @@ current stream without leaving HBM.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import numpy as np
@@ -69,6 +70,23 @@ class DeviceIndex:
     @property
     def last_path(self) -> str:
         return (lib.rag_index_last_path(self._h) or b"").decode()
+
+    # --------------------------------------------------------------- persistence
+    def save(self, path: str) -> None:
+        check(lib.rag_index_save(self._h, os.fsencode(path)))
+
+    @classmethod
+    def load(cls, path: str, device: int = 0) -> "DeviceIndex":
+        h = C.c_void_p()
+        check(lib.rag_index_load(os.fsencode(path), int(device), C.byref(h)))
+        self = cls.__new__(cls)
+        self._h = h
+        self._keepalive = None
+        self.dim = int(lib.rag_index_dim(h))
+        self.device = int(device)
+        self.kind = "flat"
+        self.metric = "snapshot"
+        return self
 
     # --------------------------------------------------------------- measurement
     def profile(self, enable: bool = True) -> None:

@@ -180,6 +180,39 @@ class HipSearchOptimizer:
         except SearchError as e:
             raise SearchError(f"Batch search failed: {e}")
 
+    # --------------------------------------------------------------- persistence
+    def backup(self, path: str) -> Dict[str, Any]:
+        """vector_db/qdrant_client.py:475-621 backup_collection: vectors as a binary
+        snapshot (`path`), payloads and point ids as a JSON sidecar (`path + ".json"`)."""
+        import json
+        self.index.save(path)
+        live = sorted(self._row_of.values())
+        with open(path + ".json", "w") as f:
+            json.dump({"collection_name": self.collection_name, "dimension": self.config.dimension,
+                       "metric": self.config.metric.value, "payloads": self.payloads, "point_ids": self.point_ids,
+                       "live_rows": live}, f)
+        return {"collection_name": self.collection_name, "points_count": len(live), "path": path}
+
+    @classmethod
+    def restore(cls, path: str, config: SearchConfig) -> "HipSearchOptimizer":
+        """vector_db/qdrant_client.py:623-764 restore_collection."""
+        import json
+        with open(path + ".json") as f:
+            meta = json.load(f)
+        if meta["dimension"] != config.dimension:
+            raise SearchError("snapshot dimension differs from the config")
+        self = cls.__new__(cls)
+        self.config = config
+        self.client = None
+        self.collection_name = config.collection_name
+        self.logger = logging.getLogger(__name__)
+        self.index = DeviceIndex.load(path, device=config.device)
+        self.payloads = meta["payloads"]
+        self.point_ids = meta["point_ids"]
+        self._row_of = {self.point_ids[r]: r for r in meta["live_rows"]}
+        self._inactive = 0
+        return self
+
     # --------------------------------------------------------------- bookkeeping
     async def get_collection_info(self) -> Dict[str, Any]:
         live = len(self._row_of)

@@ -179,3 +179,29 @@ def test_engine_semantic_hybrid_and_mmr(manager):
     want_idx = ommr.mmr_select(embs, [r.score for r in with_vec], 0.5, 5, 0.1, "cosine")
     assert [r.chunk_id for r in out] == [with_vec[i].chunk_id for i in want_idx]
     assert [r.metadata["mmr_rank"] for r in out] == [1, 2, 3, 4, 5]
+
+
+def test_backup_restore_roundtrip(tmp_path):
+    from rag_amd.schemas import MetricType, SearchConfig
+    from rag_amd.search_optimizer import HipSearchOptimizer
+    rng = np.random.default_rng(33)
+    n, d = 3000, 100                      # d % 4 == 0 but rows padded? 100 -> ld 100; also try 90 below
+    for d in (100, 90):
+        X = (rng.standard_normal((n, d)) * 2.0).astype(np.float32)
+        cfg = SearchConfig(dimension=d, metric=MetricType.COSINE, collection_name="bk")
+        opt = HipSearchOptimizer(cfg)
+        ids = [f"c{i}" for i in range(n)]
+        opt.upsert(X, [{"chunk_id": c, "document_id": 5, "text": c} for c in ids], ids)
+        opt.upsert(X[:3] * -1.0, [{"chunk_id": c, "document_id": 5, "text": "v2"} for c in ids[:3]], ids[:3])
+        q = X[10] + 0.05
+        before = run(opt.search(q.tolist(), limit=15))
+        path = str(tmp_path / f"snap{d}.bin")
+        info = opt.backup(path)
+        assert info["points_count"] == n
+        run(opt.delete_collection())
+        opt2 = HipSearchOptimizer.restore(path, cfg)
+        after = run(opt2.search(q.tolist(), limit=15))
+        assert [(c.chunk_id, s) for c, s in after] == [(c.chunk_id, s) for c, s in before]
+        assert run(opt2.get_vector_count()) == n
+        assert opt2.get_vector("c0")["payload"]["text"] == "v2"
+        run(opt2.delete_collection())
