@@ -70,6 +70,18 @@ __global__ void iota_ids_kernel(long long* ids, long long begin, long long end, 
         ids[i] = base + i;
 }
 
+int ws_acquire(rag_index* h, hipStream_t s) {
+    if (!h->ws_event) RAG_HIP_CHECK(hipEventCreateWithFlags(&h->ws_event, hipEventDisableTiming));
+    if (h->ws_pending && h->ws_stream != s) RAG_HIP_CHECK(hipStreamWaitEvent(s, h->ws_event, 0));
+    return RAG_OK;
+}
+int ws_release(rag_index* h, hipStream_t s) {
+    RAG_HIP_CHECK(hipEventRecord(h->ws_event, s));
+    h->ws_stream = s;
+    h->ws_pending = true;
+    return RAG_OK;
+}
+
 int profile_begin(rag_index* h, hipStream_t s) {
     if (!h->profiling) return RAG_OK;
     if (h->prof_used + 2 > h->prof_events.size()) {
@@ -316,6 +328,7 @@ int rag_index_free(rag_index_t* h) {
     if (h->ids_dev) (void)hipFree(h->ids_dev);
     if (h->active) (void)hipFree(h->active);
     for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
+    if (h->ws_event) (void)hipEventDestroy(h->ws_event);
     ivf_free(h);
     h->ws.release();
     h->ws2.release();
@@ -341,6 +354,7 @@ static int add_common(rag_index_t* h, int64_t n, const float* x, bool x_on_devic
     if (h->n + n > 0x7FFFFFF0LL) return fail(RAG_ERR_UNSUPPORTED, "more than 2^31 rows per index");
     if (h->kind == RAG_KIND_IVF && h->ivf.nlist == 0) return fail(RAG_ERR_INVALID, "IVF index must be trained before rows are added");
     DeviceGuard g(h->device);
+    if (int rc = ws_acquire(h, h->stream)) return rc;
     if (int rc = ensure_rows(h, n)) return rc;
     const int normalize = h->metric == RAG_METRIC_COSINE;
     float* dst = h->X + (size_t)h->n * h->ld;
@@ -438,6 +452,7 @@ int rag_index_set_active(rag_index_t* h, int64_t n, const int64_t* rows, int act
         RAG_HIP_CHECK(hipMalloc((void**)&h->active, (size_t)std::max<long long>(h->cap, 1)));
         RAG_HIP_CHECK(hipMemset(h->active, 1, (size_t)std::max<long long>(h->cap, 1)));
     }
+    if (int rc = ws_acquire(h, h->stream)) return rc;
     if (int rc = h->ws2.ensure((size_t)n * sizeof(long long))) return rc;
     RAG_HIP_CHECK(hipMemcpyAsync(h->ws2.ptr, rows, (size_t)n * sizeof(long long), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(scatter_bytes_kernel, dim3(grid_for(n)), dim3(256), 0, h->stream, h->active,
@@ -455,6 +470,7 @@ int rag_index_reconstruct(rag_index_t* h, int64_t n, const int64_t* rows, float*
         if (rows[i] < 0 || rows[i] >= h->n) return fail(RAG_ERR_INVALID, "row " + std::to_string(rows[i]) + " out of range");
     DeviceGuard g(h->device);
     const size_t rbytes = ((size_t)n * sizeof(long long) + 255) & ~(size_t)255;
+    if (int rc = ws_acquire(h, h->stream)) return rc;
     if (int rc = h->ws2.ensure(rbytes + (size_t)n * h->dim * sizeof(float))) return rc;
     long long* drows = static_cast<long long*>(h->ws2.ptr);
     float* dout = reinterpret_cast<float*>(static_cast<char*>(h->ws2.ptr) + rbytes);
@@ -472,6 +488,9 @@ int rag_index_reconstruct(rag_index_t* h, int64_t n, const int64_t* rows, float*
     return RAG_OK;
 }
 
+static int search_device_ordered(rag_index* h, int64_t nq, const float* q_dev, int k, float min_score, int nprobe,
+                                 const uint8_t* row_mask_dev, float* D_dev, int64_t* I_dev, hipStream_t s);
+
 int rag_index_search_device(rag_index_t* h, int64_t nq, const float* q_dev, int k, float min_score, int nprobe,
                             const uint8_t* row_mask_dev, float* D_dev, int64_t* I_dev, void* stream) {
     if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
@@ -482,6 +501,14 @@ int rag_index_search_device(rag_index_t* h, int64_t nq, const float* q_dev, int 
     if (min_score != min_score) return fail(RAG_ERR_INVALID, "min_score is NaN");
     DeviceGuard g(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = ws_acquire(h, s)) return rc;
+    const int rc = search_device_ordered(h, nq, q_dev, k, min_score, nprobe, row_mask_dev, D_dev, I_dev, s);
+    if (rc) return rc;
+    return ws_release(h, s);
+}
+
+static int search_device_ordered(rag_index* h, int64_t nq, const float* q_dev, int k, float min_score, int nprobe,
+                                 const uint8_t* row_mask_dev, float* D_dev, int64_t* I_dev, hipStream_t s) {
     long long* I = reinterpret_cast<long long*>(I_dev);
     if (h->n == 0) {
         hipLaunchKernelGGL(fill_results_kernel, dim3(grid_for(nq * k)), dim3(256), 0, s, D_dev, I, (long long)nq * k);
@@ -562,6 +589,7 @@ int rag_index_search_segments(rag_index_t* h, int64_t nq, const float* q, int64_
     }
     DeviceGuard g(h->device);
     hipStream_t s = h->stream;
+    if (int rc = ws_acquire(h, s)) return rc;
     // effective mask
     const uint8_t* mask = nullptr;
     const size_t mb = (((size_t)h->n + 255) & ~(size_t)255);
@@ -639,6 +667,7 @@ int rag_index_search_segments(rag_index_t* h, int64_t nq, const float* q, int64_
     RAG_HIP_CHECK(hipMemcpyAsync(D, D_dev, (size_t)nq * nseg * k * sizeof(float), hipMemcpyDeviceToHost, s));
     RAG_HIP_CHECK(hipMemcpyAsync(I, I_dev, (size_t)nq * nseg * k * sizeof(long long), hipMemcpyDeviceToHost, s));
     RAG_HIP_CHECK(hipStreamSynchronize(s));
+    h->ws_pending = false;
     h->last_path = "segments";
     return RAG_OK;
 }

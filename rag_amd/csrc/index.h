@@ -36,6 +36,13 @@ struct Workspace {
 int profile_begin(rag_index* h, hipStream_t s);
 int profile_end(rag_index* h, hipStream_t s);
 
+// The workspaces of an index are shared by every search on it.  Work enqueued on
+// stream `s` first waits for the previous user of the workspaces when that user
+// ran on another stream (ws_acquire), and marks its own end (ws_release), so
+// back-to-back searches on different streams are ordered on the device.
+int ws_acquire(rag_index* h, hipStream_t s);
+int ws_release(rag_index* h, hipStream_t s);
+
 // IVF bookkeeping.  Rows are stored grouped by list ("storage order"); ids, the
 // soft-delete bytes and every caller-visible row number stay in insertion order.
 struct IvfState {
@@ -71,6 +78,9 @@ struct rag_index {
     rag::Workspace ws;              // queries, partial keys, staging
     rag::Workspace ws2;             // combined masks, host-API result staging
     hipStream_t stream = nullptr;   // used by the host-pointer entry points
+    hipEvent_t ws_event = nullptr;  // end of the last work that used ws / ws2
+    hipStream_t ws_stream = nullptr;
+    bool ws_pending = false;
     const char* last_path = "none";
     rag::IvfState ivf;
     // measurement: event pairs around the dominant kernel of each search

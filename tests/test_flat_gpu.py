@@ -186,6 +186,35 @@ def test_torch_device_path_and_adopt():
     idx2.close()
 
 
+def test_searches_on_different_streams_are_ordered():
+    """A device search queued on torch's stream, a host-pointer search (the index's
+    own stream) and a search on a side stream share the index workspaces; the
+    library orders them, so none sees the other's queries or partial lists."""
+    import torch
+    from rag_amd import DeviceIndex
+    rng = np.random.default_rng(23)
+    n, d, k = 400_000, 768, 10
+    X = _unit(rng, n, d)
+    Q = _unit(rng, 9, d)
+    xt = torch.from_numpy(X).cuda()
+    qt = torch.from_numpy(Q).cuda()
+    idx = DeviceIndex(d, metric="ip")
+    idx.adopt(xt)
+    side = torch.cuda.Stream()
+    for _ in range(5):
+        Da, Ia = idx.search(qt[:3], k)                       # async, torch's current stream
+        Dh, Ih = idx.search(Q[3:6], k)                       # host API, index stream, blocking
+        with torch.cuda.stream(side):
+            Ds, Is = idx.search(qt[6:9], k)                  # async, side stream
+        Dseg, Iseg = idx.search_segments(Q[:2], [(0, n)], k)
+        torch.cuda.synchronize()
+        _check(Da.cpu().numpy(), Ia.cpu().numpy(), X, Q[:3], k)
+        _check(Dh, Ih, X, Q[3:6], k)
+        _check(Ds.cpu().numpy(), Is.cpu().numpy(), X, Q[6:9], k)
+        _check(Dseg[:, 0], Iseg[:, 0], X, Q[:2], k)
+    idx.close()
+
+
 def test_merge_topk_device():
     import torch
     from rag_amd import DeviceIndex, merge_topk
