@@ -20,9 +20,26 @@ nlist = int(os.environ.get("NLIST", 16384))
 nprobe = int(os.environ.get("NPROBE", 64))
 k = 10
 dev = torch.device("cuda", 0)
-X = make_corpus(torch, 0, rows, dim, dev)
-Q = make_queries(torch, 256, dim, dev)
-cent = X[torch.arange(0, rows, rows // nlist, device=dev)[:nlist]].cpu().numpy()
+clustered = os.environ.get("CLUSTERED", "1") == "1"
+if clustered:
+    # nlist unit centres, each row = its centre + noise of norm ~0.6, re-normalised;
+    # a query = a corpus row + noise of norm ~0.3: its neighbours sit in few lists
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    C = torch.nn.functional.normalize(torch.randn(nlist, dim, device=dev, generator=g), dim=1)
+    X = torch.empty(rows, dim, device=dev)
+    for r0 in range(0, rows, 500_000):
+        c = min(500_000, rows - r0)
+        a = torch.randint(0, nlist, (c,), device=dev, generator=g)
+        X[r0:r0 + c] = torch.nn.functional.normalize(
+            C[a] + (0.6 / dim ** 0.5) * torch.randn(c, dim, device=dev, generator=g), dim=1)
+    pick = torch.randint(0, rows, (256,), device=dev, generator=g)
+    Q = torch.nn.functional.normalize(X[pick] + (0.3 / dim ** 0.5) * torch.randn(256, dim, device=dev, generator=g), dim=1)
+    cent = C.cpu().numpy()
+else:
+    X = make_corpus(torch, 0, rows, dim, dev)
+    Q = make_queries(torch, 256, dim, dev)
+    cent = X[torch.arange(0, rows, rows // nlist, device=dev)[:nlist]].cpu().numpy()
 ivf = DeviceIndex(dim, metric="ip", kind="ivf")
 ivf.train_ivf(nlist, centroids=cent)
 ivf.reserve(rows)
@@ -37,7 +54,7 @@ torch.cuda.synchronize()
 t_pack = time.perf_counter() - t0
 flat = DeviceIndex(dim, metric="ip")
 flat.adopt(X)
-out = {"rows": rows, "dim": dim, "nlist": nlist, "nprobe": nprobe, "add_assign_s": t_add, "first_search_pack_s": t_pack}
+out = {"clustered_corpus": clustered, "rows": rows, "dim": dim, "nlist": nlist, "nprobe": nprobe, "add_assign_s": t_add, "first_search_pack_s": t_pack}
 for nq, steps in ((1, 50), (256, 5)):
     ivf.profile(True)
     ivf.search(Q[:nq], k, nprobe=nprobe)

@@ -22,7 +22,7 @@ Q = make_queries(torch, max(nq, 64), dim, dev)
 idx = DeviceIndex(dim, metric="ip")
 idx.adopt(X)
 idx.profile(True)
-for i in range(5):
+for i in range(int(os.environ.get("WARMUP", 5))):
     idx.search(Q[:nq], k)
 torch.cuda.synchronize()
 idx.profile_read(True)
