@@ -210,11 +210,13 @@ static int flat_scan_search(rag_index* h, long long nq, const float* qbuf, int k
     const int cap = merge_cap((long long)waves * k, k);
     long long q0 = 0;
     while (q0 < nq) {
+        // queries per pass: 8, or the next power of two above what is left (a pass costs one
+        // read of the corpus however many of its query slots are used; the surplus slots repeat
+        // the last query and their lists are never merged)
         int g = 1;
-        if (k <= 64) {
-            const long long left = nq - q0;
-            g = left >= 8 ? 8 : left >= 4 ? 4 : left >= 2 ? 2 : 1;
-        }
+        const long long left = nq - q0;
+        if (k <= 64) g = left >= 8 ? 8 : pow2_ceil((int)left);
+        const int real = (int)std::min<long long>(left, g);
         ScanArgs a = {};
         a.X = h->X;
         a.Q = qbuf + q0 * h->ld;
@@ -231,6 +233,7 @@ static int flat_scan_search(rag_index* h, long long nq, const float* qbuf, int k
         a.ivf_nprobe = 0;
         a.ivf_slices = 1;
         a.grid_y = 1;
+        a.nq_valid = real;
         // rows larger than the Infinity Cache are streamed; smaller corpora stay cacheable
         static const int nt_mode = env_int("RAG_SCAN_NT", -1);
         a.nt = nt_mode >= 0 ? nt_mode : ((size_t)h->n * h->ld * sizeof(float) > (192ull << 20) ? 1 : 0);
@@ -249,8 +252,8 @@ static int flat_scan_search(rag_index* h, long long nq, const float* qbuf, int k
         m.slot_stride = 0;
         m.D = D + q0 * k;
         m.I = I + q0 * k;
-        RAG_HIP_CHECK(launch_merge_keys(m, g, s));
-        q0 += g;
+        RAG_HIP_CHECK(launch_merge_keys(m, real, s));
+        q0 += real;
     }
     h->last_path = "scan";
     return RAG_OK;

@@ -105,7 +105,11 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(ScanArgs a) {
             qf[c] = (col < d4) ? Q4[col] : f4_zero();
         }
     } else {
-        for (int i = threadIdx.x; i < NQ * d4; i += 256) qlds[i] = Q4[i];
+        const int valid = (a.nq_valid > 0 && a.nq_valid < NQ) ? a.nq_valid : NQ;
+        for (int i = threadIdx.x; i < NQ * d4; i += 256) {
+            const int qi = i / d4;
+            qlds[i] = Q4[qi < valid ? i : i - (qi - (valid - 1)) * d4];
+        }
         __syncthreads();
     }
     // wave-private LDS candidate buffer (BIGK), placed after the query image

@@ -5,33 +5,36 @@
 // work per launch = 2 * nq * n * ld flops.  Scores are bit-for-bit a k-ordered
 // fp32 fma chain, the same arithmetic a CPU inner product performs.
 //
-// Tiling.  A workgroup (4 waves) owns a block of 128 queries and a contiguous
-// range of corpus rows, which it walks in tiles of 128 rows.  Per tile it runs
+// Tiling.  A workgroup (4 waves) owns a block of QT queries and a contiguous
+// range of corpus rows, which it walks in tiles of RT rows.  Per tile it runs
 // the K loop in steps of 32 through LDS (double buffered, one barrier per step;
 // the next step's global loads are in flight while the current step computes).
-// Each wave holds a 64 x 64 piece of the 128 x 128 score tile as 2 x 2 MFMA
-// accumulators.  Corpus rows sit on the MFMA's row index (registers), queries on
-// its column index (lanes): a lane owns two queries and sees 2 x 32 rows of each.
+// Three shapes, chosen by the batch size:
+//      RT x QT     waves (rows x queries)   per wave            used for
+//      128 x 128   2 x 2                    64 x 64, 2x2 MFMA   nq > 64
+//      128 x 64    2 x 2                    64 x 32, 2x1 MFMA   32 < nq <= 64
+//      256 x 32    4 x 1                    64 x 32, 2x1 MFMA   nq <= 32
+// The narrow shapes spend no matrix-core time on padding queries: a batch of 32
+// costs about one HBM pass over the corpus instead of a 128-query tile's work.
+// Corpus rows sit on the MFMA's row index (registers), queries on its column
+// index (lanes): a lane owns NJ queries and sees 2 x 32 rows of each.
 //
 // A lane reads k = 8*kb + 4*h + s (h = lane >> 5, s = 0..3) of its row as one
 // ds_read_b128 and feeds element s to MFMA step s; both operands use the same k
 // order, so the sum over (h, s) covers the 8 k's of the block exactly once.
 //
-// Staging, two variants (same results):
-//   DMA = true   global_load_lds_dwordx4 writes the tiles straight into LDS (no
-//                staging registers, no ds_write).  The LDS image is dense
-//                [128 rows][8 x 16 B]; the 16-byte chunk c of row r sits at
-//                position c ^ ((r >> 1) & 7), applied on the SOURCE address of
-//                the DMA and again on the fragment read, which makes the reads
-//                of any 16 rows that differ mod 16 hit 16 different bank groups.
-//   DMA = false  registers + ds_write_b128 into rows padded to 36 floats.
+// Staging.  global_load_lds_dwordx4 writes the tiles straight into LDS (no
+// staging registers, no ds_write).  The LDS image is dense [rows][8 x 16 B]; the
+// 16-byte chunk c of row r sits at position c ^ ((r >> 1) & 7), applied on the
+// SOURCE address of the DMA and again on the fragment read, which makes the reads
+// of any 16 rows that differ mod 16 hit 16 different bank groups.
 //
 // Selection.  Per query the workgroup keeps a threshold (LDS) and a candidate
-// buffer of 256 keys (global memory, private to the workgroup, L2 resident).  A
+// buffer of TRIG + RT keys (global memory, private to the workgroup, L2 resident).  A
 // score enters the buffer only if it beats the threshold, which after the first
 // few tiles is rare: the epilogue is a max tree + one ballot per wave, and only
 // a wave with a hit walks its accumulators.  When a query's buffer could
-// overflow on the next tile (count > 256 - 128) one wave sorts it in LDS, keeps k
+// overflow on the next tile (count > TRIG) one wave sorts it in LDS, keeps k
 // and tightens the threshold.  At the end every query's k best keys go to `part`,
 // and merge_keys_kernel merges the row-range partials.
 //
@@ -48,14 +51,21 @@ int merge_cap(long long per_query, int k);
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 
-constexpr int GT = 128;          // tile edge: rows and queries
 constexpr int GK = 32;           // K step
-constexpr int GLD = GK + 4;      // padded LDS row stride (floats), register-staged variant
-constexpr int CAPQ = 256;        // candidate keys per query per workgroup
 constexpr int GEMM_MAX_K = 64;
 
+// A query's candidate buffer is compacted (sorted, cut to k, threshold tightened) once it holds
+// more than TRIG keys at the end of a tile; a tile adds at most RT, so it holds TRIG + RT.
+// Narrow shapes see few rows per workgroup (the corpus is split 512 ways for a single query
+// block), so they tighten early and often; the square shape streams long ranges and rarely compacts.
+__host__ __device__ constexpr int gemm_trig(int RT, int QT) { return QT == 128 ? RT : 64; }
+__host__ __device__ constexpr int gemm_capq(int RT, int QT) { return gemm_trig(RT, QT) + RT; }
+
 // Timing-only ablations for diagnostic builds (outputs are wrong when non-zero):
-// bit 0 skip the tile epilogue, bit 1 load global tiles only once, bit 2 stage LDS only twice.
+// bit 0 skip the tile epilogue, bit 1 load global tiles only once, bit 2 barrier only twice,
+// bit 3 walk the accumulators but push nothing, bit 4 stop after the epilogue's ballot,
+// bit 5 no sort inside a compaction, bit 6 no sort in the final pass, bit 7 pushes store nothing,
+// bit 8 pushes skip the LDS counter, bit 9 count and print events of two workgroups.
 #ifndef RAG_GEMM_DIAG
 #define RAG_GEMM_DIAG 0
 #endif
@@ -65,7 +75,7 @@ struct GemmArgs {
     const float* X;
     const float* Q;
     const uint8_t* mask;
-    u64* cand;       // [grid][GT][CAPQ]
+    u64* cand;       // [grid][QT][TRIG + RT]
     u64* part;       // [nq][S][k]
     long long n;
     long long ntiles;
@@ -77,24 +87,35 @@ struct GemmArgs {
     int S;           // row ranges
 };
 
-// rare path of the tile epilogue, kept out of line so that the 64 call sites stay small
-__device__ __attribute__((noinline)) void push_candidate(const GemmArgs& a, u64* cand, int* s_cnt, int* s_flag, int ql,
+// rare path of the tile epilogue, kept out of line so that the call sites stay small
+#ifndef RAG_GEMM_NARROW_AUX
+#define RAG_GEMM_NARROW_AUX 2
+#endif
+#ifndef RAG_GEMM_PUSH_ATTR
+#define RAG_GEMM_PUSH_ATTR __attribute__((noinline))
+#endif
+template <int RT, int QT>
+__device__ RAG_GEMM_PUSH_ATTR void push_candidate(const GemmArgs& a, u64* cand, int* s_cnt, int* s_flag, int ql,
                                                          long long row, float sc) {
+    constexpr int CAPQ = gemm_capq(RT, QT);
     if (row < a.n && (!a.mask || a.mask[row])) {
-        const int pos = atomicAdd(&s_cnt[ql], 1);
-        cand[(size_t)ql * CAPQ + pos] = make_key(sc, (uint32_t)row);
-        if (pos + 1 > CAPQ - GT) *s_flag = 1;       // compact before the next tile can overflow it
+        if (DIAG & 512) atomicAdd(&s_flag[1], 1);
+        const int pos = (DIAG & 256) ? 0 : atomicAdd(&s_cnt[ql], 1);
+        if (!(DIAG & 128)) cand[(size_t)ql * CAPQ + pos] = make_key(sc, (uint32_t)row);
+        if (pos + 1 > gemm_trig(RT, QT)) *s_flag = 1;       // compact before the next tile can overflow it
     }
 }
 
-// one wave per query: sort the candidate buffer of every query that could overflow on the
-// next tile (all == false) or of every query (all == true, final pass writing `out`)
+// one wave per query: sort the candidate buffer of every query that could overflow on the next tile
+template <int RT, int QT>
 __device__ __forceinline__ void compact_queries(u64* scratch, u64* cand, int* s_cnt, float* s_thr, int k, int wave, int lane) {
-    for (int ql = wave; ql < GT; ql += 4) {
+    constexpr int CAPQ = gemm_capq(RT, QT);
+    for (int ql = wave; ql < QT; ql += 4) {
         const int c = s_cnt[ql];
-        if (c <= CAPQ - GT) continue;            // wave-uniform
-        for (int i = lane; i < CAPQ; i += 64) scratch[i] = (i < c) ? cand[(size_t)ql * CAPQ + i] : KEY_EMPTY;
-        bitonic_sort_desc_lds(scratch, CAPQ, lane, 64, SyncWave());
+        if (c <= gemm_trig(RT, QT)) continue;            // wave-uniform
+        const int n2 = pow2_ceil(c > k ? c : k);
+        for (int i = lane; i < n2; i += 64) scratch[i] = (i < c) ? cand[(size_t)ql * CAPQ + i] : KEY_EMPTY;
+        if (!(DIAG & 32)) bitonic_sort_desc_lds(scratch, n2, lane, 64, SyncWave());
         for (int i = lane; i < k; i += 64) cand[(size_t)ql * CAPQ + i] = scratch[i];
         if (lane == 0) {
             s_cnt[ql] = c < k ? c : k;
@@ -104,16 +125,18 @@ __device__ __forceinline__ void compact_queries(u64* scratch, u64* cand, int* s_
     }
 }
 
-// Tile epilogue.  A lane owns two queries and 32 scores of each.  First the cheap test "does
+// Tile epilogue.  A lane owns NJ queries and 2 x 16 scores of each.  First the cheap test "does
 // any of my scores beat its query's threshold" (a max tree and one ballot); only a wave
-// with a hit walks its accumulators.
-__device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f16v (&acc)[2][2], u64* cand, float* s_thr, int* s_cnt,
-                                              int* s_flag, int q0, long long n0, int wm, int wq, int l31, int h) {
-    float thr[2];
+// with a hit walks its accumulators.  rbase = first corpus row of this wave's 64, qbase =
+// first query (within the block) of this wave's NJ * 32.
+template <int RT, int QT, int NJ>
+__device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f16v (&acc)[2][NJ], u64* cand, float* s_thr, int* s_cnt,
+                                              int* s_flag, int q0, long long rbase, int qbase, int l31, int h) {
+    float thr[NJ];
     bool hit = false;
 #pragma unroll
-    for (int nj = 0; nj < 2; ++nj) {
-        const int ql = wq * 64 + nj * 32 + l31;
+    for (int nj = 0; nj < NJ; ++nj) {
+        const int ql = qbase + nj * 32 + l31;
         thr[nj] = (q0 + ql) < a.nq ? s_thr[ql] : INFINITY;
         float m = -INFINITY;
 #pragma unroll
@@ -123,38 +146,52 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f16v (&acc)[2][
         hit |= m > thr[nj];
     }
     if (__ballot(hit) != 0ull) {
+        if ((DIAG & 512) && (threadIdx.x & 63) == 0) atomicAdd(&s_flag[3], 1);
+        if (DIAG & 16) { if (thr[0] == 123.456f) *s_flag = 1; return; }
 #pragma unroll
-        for (int nj = 0; nj < 2; ++nj) {
-            const int ql = wq * 64 + nj * 32 + l31;
+        for (int nj = 0; nj < NJ; ++nj) {
+            const int ql = qbase + nj * 32 + l31;
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float sc = acc[mi][nj][r];
-                    if (sc > thr[nj])
-                        push_candidate(a, cand, s_cnt, s_flag, ql, n0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, sc);
+                    if (sc > thr[nj] && (!(DIAG & 8) || sc == 123.456f))
+                        push_candidate<RT, QT>(a, cand, s_cnt, s_flag, ql, rbase + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, sc);
                 }
             }
         }
     }
 }
 
-template <bool DMA>
+template <int RT, int QT>
 __global__ __launch_bounds__(256, 2) void gemm_topk_kernel(GemmArgs a) {
-    constexpr int ROWF = DMA ? GK : GLD;                 // floats per LDS tile row
-    constexpr int TILEF = GT * ROWF;                     // floats per operand tile
+    constexpr int WM = RT / 64;              // waves along the corpus rows
+    constexpr int WQ = 4 / WM;               // waves along the queries
+    constexpr int NJ = QT / WQ / 32;         // 32-query MFMA columns per wave
+    constexpr int CAPQ = gemm_capq(RT, QT);
+    constexpr int CAPQ2 = CAPQ <= 256 ? 256 : 512;      // sort size bound (power of two)
+    constexpr int APW = RT / 32;             // 1-KiB DMA pieces (8 rows x 128 B) per wave and K step, corpus
+    constexpr int BPW = QT / 32;             //   ... queries
+    constexpr int TILEA = RT * GK;           // floats per corpus stage
+    constexpr int TILEB = QT * GK;
+    // cache policy of the corpus loads: a single query block reads every row once (non-temporal,
+    // bit 1); with many query blocks the rows are re-read by other workgroups and should stay cached
+    constexpr int A_AUX = (QT == 128) ? 0 : RAG_GEMM_NARROW_AUX;
+    static_assert(WM * WQ == 4 && NJ >= 1 && WM * 64 == RT && WQ * NJ * 32 == QT, "tile shape");
+    static_assert(4 * CAPQ2 * 8 <= TILEA * 4, "compaction scratch must fit in one idle corpus stage");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* As = reinterpret_cast<float*>(smem);                       // [2][TILEF] corpus rows
-    float* Bs = As + 2 * TILEF;                                        // [2][TILEF] queries
-    float* s_thr = Bs + 2 * TILEF;                                     // [GT]
-    int* s_cnt = reinterpret_cast<int*>(s_thr + GT);                   // [GT]
-    int* s_flag = s_cnt + GT;                                          // [1] (+3 pad)
+    float* As = reinterpret_cast<float*>(smem);                       // [2][TILEA] corpus rows
+    float* Bs = As + 2 * TILEA;                                        // [2][TILEB] queries
+    float* s_thr = Bs + 2 * TILEB;                                     // [QT]
+    int* s_cnt = reinterpret_cast<int*>(s_thr + QT);                   // [QT]
+    int* s_flag = s_cnt + QT;                                          // [1] (+3 pad)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1;        // which 64 corpus rows of the tile
-    const int wq = wave & 1;         // which 64 queries of the block
+    const int wm = wave / WQ;        // which 64 corpus rows of the tile
+    const int wq = wave % WQ;        // which NJ*32 queries of the block
     const int l31 = lane & 31;
     const int h = lane >> 5;
 
@@ -162,15 +199,15 @@ __global__ __launch_bounds__(256, 2) void gemm_topk_kernel(GemmArgs a) {
     const int qb = b % a.nqb_pad;
     const int sp = b / a.nqb_pad;
     if (qb >= a.nqb) return;
-    const int q0 = qb * GT;
+    const int q0 = qb * QT;
     const int k = a.k;
     const int KT = a.ld / GK;
     const long long t_begin = a.ntiles * sp / a.S;
     const long long t_end = a.ntiles * (sp + 1) / a.S;
-    u64* cand = a.cand + (size_t)b * GT * CAPQ;
+    u64* cand = a.cand + (size_t)b * QT * CAPQ;
 
-    for (int i = tid; i < GT; i += 256) { s_thr[i] = -INFINITY; s_cnt[i] = 0; }
-    if (tid == 0) *s_flag = 0;
+    for (int i = tid; i < QT; i += 256) { s_thr[i] = -INFINITY; s_cnt[i] = 0; }
+    if (tid == 0) { *s_flag = 0; if (DIAG & 512) { s_flag[1] = 0; s_flag[2] = 0; s_flag[3] = 0; } }
     __syncthreads();
 
     const f4* X4 = reinterpret_cast<const f4*>(a.X);
@@ -178,78 +215,51 @@ __global__ __launch_bounds__(256, 2) void gemm_topk_kernel(GemmArgs a) {
     const int ld4 = a.ld / 4;
 
     // ---- loader ------------------------------------------------------------------------
-    // DMA: wave instruction i (0..3) fills tile rows (4*wave + i)*8 .. +7, lane -> (row = lane>>3,
-    //      position = lane&7); the chunk fetched for a position is position ^ ((row>>1)&7).
-    // registers: thread -> rows (tid>>3) + 32*i, chunk tid&7.
+    // wave instruction i fills tile rows (APW*wave + i)*8 .. +7 (queries: BPW), lane -> (row = lane>>3,
+    // position = lane&7); the chunk fetched for a position is position ^ ((row>>1)&7).
     const int wv = __builtin_amdgcn_readfirstlane(wave);
-    int trow[4], tchunk[4];
+    int arow[APW], achunk[APW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if constexpr (DMA) {
-            trow[i] = (wv * 4 + i) * 8 + (lane >> 3);
-            tchunk[i] = (lane & 7) ^ ((trow[i] >> 1) & 7);
-        } else {
-            trow[i] = (tid >> 3) + 32 * i;
-            tchunk[i] = tid & 7;
-        }
+    for (int i = 0; i < APW; ++i) {
+        arow[i] = (wv * APW + i) * 8 + (lane >> 3);
+        achunk[i] = (lane & 7) ^ ((arow[i] >> 1) & 7);
     }
-    const f4* qp[4];
-    const f4* xp[4];
+    const f4* qp[BPW];
+    const f4* xp[APW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int qr = q0 + trow[i];
+    for (int i = 0; i < BPW; ++i) {
+        const int brow = (wv * BPW + i) * 8 + (lane >> 3);
+        int qr = q0 + brow;
         qr = qr < a.nq ? qr : a.nq - 1;
-        qp[i] = Q4 + (long long)qr * ld4 + tchunk[i];
+        qp[i] = Q4 + (long long)qr * ld4 + ((lane & 7) ^ ((brow >> 1) & 7));
     }
     auto set_tile = [&](long long t) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            long long r = t * GT + trow[i];
+        for (int i = 0; i < APW; ++i) {
+            long long r = t * RT + arow[i];
             r = r < a.n ? r : a.n - 1;
-            xp[i] = X4 + r * ld4 + tchunk[i];
+            xp[i] = X4 + r * ld4 + achunk[i];
         }
     };
-    f4 xr[DMA ? 1 : 4], qr4[DMA ? 1 : 4];
     // request the tiles of K step kt (of the tile xp points at) for LDS buffer `buf`
     auto issue_load = [&](int kt, int buf) {
-        if constexpr (DMA) {
-            unsigned char* Ab = reinterpret_cast<unsigned char*>(As + buf * TILEF) + wv * 4096;
-            unsigned char* Bb = reinterpret_cast<unsigned char*>(Bs + buf * TILEF) + wv * 4096;
+        unsigned char* Ab = reinterpret_cast<unsigned char*>(As + buf * TILEA) + wv * (APW * 1024);
+        unsigned char* Bb = reinterpret_cast<unsigned char*>(Bs + buf * TILEB) + wv * (BPW * 1024);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xp[i] + kt * (GK / 4)),
-                                                 (__attribute__((address_space(3))) void*)(Ab + i * 1024), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qp[i] + kt * (GK / 4)),
+        for (int i = 0; i < APW; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xp[i] + kt * (GK / 4)),
+                                             (__attribute__((address_space(3))) void*)(Ab + i * 1024), 16, 0, A_AUX);
+            if (i < BPW)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qp[i < BPW ? i : 0] + kt * (GK / 4)),
                                                  (__attribute__((address_space(3))) void*)(Bb + i * 1024), 16, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                xr[i] = xp[i][kt * (GK / 4)];
-                qr4[i] = qp[i][kt * (GK / 4)];
-            }
-        }
-    };
-    auto store_lds = [&](int buf) {
-        if constexpr (!DMA) {
-            float* Ab = As + buf * TILEF + (tid >> 3) * GLD + (tid & 7) * 4;
-            float* Bb = Bs + buf * TILEF + (tid >> 3) * GLD + (tid & 7) * 4;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                *reinterpret_cast<f4*>(Ab + i * 32 * GLD) = xr[i];
-                *reinterpret_cast<f4*>(Bb + i * 32 * GLD) = qr4[i];
-            }
         }
     };
     // fragment read offsets (floats) of this lane inside an operand tile, per 8-wide k block
     int foff[GK / 8];
 #pragma unroll
-    for (int kb = 0; kb < GK / 8; ++kb) {
-        if constexpr (DMA) foff[kb] = l31 * GK + (((kb * 2 + h) ^ ((l31 >> 1) & 7)) << 2);
-        else foff[kb] = l31 * GLD + kb * 8 + h * 4;
-    }
+    for (int kb = 0; kb < GK / 8; ++kb) foff[kb] = l31 * GK + (((kb * 2 + h) ^ ((l31 >> 1) & 7)) << 2);
 
-    f16v acc[2][2];
+    f16v acc[2][NJ];
     int buf = 0;
     if (t_begin < t_end) {
         set_tile(t_begin);
@@ -259,55 +269,55 @@ __global__ __launch_bounds__(256, 2) void gemm_topk_kernel(GemmArgs a) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int nj = 0; nj < 2; ++nj)
+            for (int nj = 0; nj < NJ; ++nj)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][nj][r] = 0.f;
         for (int kt = 0; kt < KT; ++kt, buf ^= 1) {
-            if (!(DIAG & 4) || (t == t_begin && kt < 2)) {
-                store_lds(buf);
-                __syncthreads();     // stage `buf` is complete (an LDS-DMA in flight is drained here too)
-            }
+            if (!(DIAG & 4) || (t == t_begin && kt < 2))
+                __syncthreads();     // stage `buf` is complete (the LDS-DMA in flight is drained here too)
             // a candidate buffer filled up during the previous tile's epilogue: every wave has
             // passed the barrier above, so the flag is stable and stage buf^1 is idle
             if (kt == 0 && *s_flag != 0) {
-                compact_queries(reinterpret_cast<u64*>(As + (buf ^ 1) * TILEF) + wave * CAPQ, cand, s_cnt, s_thr, k, wave, lane);
+                compact_queries<RT, QT>(reinterpret_cast<u64*>(As + (buf ^ 1) * TILEA) + wave * CAPQ2, cand, s_cnt, s_thr, k, wave, lane);
                 __syncthreads();
                 if (tid == 0) *s_flag = 0;
+                if ((DIAG & 512) && tid == 0) s_flag[2] += 1;
             }
             if (!(DIAG & 2) || (t == t_begin && kt == 0)) {
                 if (kt + 1 < KT) issue_load(kt + 1, buf ^ 1);
                 else if (t + 1 < t_end) { set_tile(t + 1); issue_load(0, buf ^ 1); }
             }
-            const float* Ab = As + buf * TILEF + (wm * 64) * ROWF;
-            const float* Bb = Bs + buf * TILEF + (wq * 64) * ROWF;
+            const float* Ab = As + buf * TILEA + (wm * 64) * GK;
+            const float* Bb = Bs + buf * TILEB + (wq * NJ * 32) * GK;
             // fragments of k block kb+1 are requested while the MFMAs of block kb issue: one
-            // ds_read_b128 in front of every four MFMAs (two register sets, kb parity)
-            f4 fa0[2], fa1[2], fb0[2], fb1[2];
-            fa0[0] = *reinterpret_cast<const f4*>(Ab + foff[0]);
-            fa1[0] = *reinterpret_cast<const f4*>(Ab + 32 * ROWF + foff[0]);
-            fb0[0] = *reinterpret_cast<const f4*>(Bb + foff[0]);
-            fb1[0] = *reinterpret_cast<const f4*>(Bb + 32 * ROWF + foff[0]);
+            // ds_read_b128 in front of every few MFMAs (two register sets, kb parity)
+            f4 fa[2][2], fb[2][NJ];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) fa[0][mi] = *reinterpret_cast<const f4*>(Ab + mi * 32 * GK + foff[0]);
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj) fb[0][nj] = *reinterpret_cast<const f4*>(Bb + nj * 32 * GK + foff[0]);
 #pragma unroll
             for (int kb = 0; kb < GK / 8; ++kb) {
                 const int cur = kb & 1, nxt = cur ^ 1;
                 if (kb + 1 < GK / 8) {
-                    fa0[nxt] = *reinterpret_cast<const f4*>(Ab + foff[kb + 1]);
-                    fa1[nxt] = *reinterpret_cast<const f4*>(Ab + 32 * ROWF + foff[kb + 1]);
-                    fb0[nxt] = *reinterpret_cast<const f4*>(Bb + foff[kb + 1]);
-                    fb1[nxt] = *reinterpret_cast<const f4*>(Bb + 32 * ROWF + foff[kb + 1]);
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) fa[nxt][mi] = *reinterpret_cast<const f4*>(Ab + mi * 32 * GK + foff[kb + 1]);
+#pragma unroll
+                    for (int nj = 0; nj < NJ; ++nj) fb[nxt][nj] = *reinterpret_cast<const f4*>(Bb + nj * 32 * GK + foff[kb + 1]);
                 }
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[cur][s], fb0[cur][s], acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[cur][s], fb1[cur][s], acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[cur][s], fb0[cur][s], acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[cur][s], fb1[cur][s], acc[1][1], 0, 0, 0);
-                }
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int nj = 0; nj < NJ; ++nj)
+                            acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][mi][s], fb[cur][nj][s], acc[mi][nj], 0, 0, 0);
                 if (kb + 1 < GK / 8) {
+                    constexpr int READS = 2 + NJ, MFMAS = 8 * NJ;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
-                        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // 4 MFMA
+                    for (int j = 0; j < READS; ++j) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);               // 1 DS read
+                        __builtin_amdgcn_sched_group_barrier(0x008, MFMAS / READS, 0);   // a share of the MFMAs
                     }
                 }
             }
@@ -315,22 +325,29 @@ __global__ __launch_bounds__(256, 2) void gemm_topk_kernel(GemmArgs a) {
         if (DIAG & 1) {
             float keep = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) keep += acc[0][0][r] + acc[0][1][r] + acc[1][0][r] + acc[1][1][r];
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) keep += acc[mi][nj][r];
             if (keep == 123.456f) s_thr[0] = keep;      // keeps the accumulators live
             continue;
         }
-        tile_epilogue(a, acc, cand, s_thr, s_cnt, s_flag, q0, t * GT, wm, wq, l31, h);
+        tile_epilogue<RT, QT, NJ>(a, acc, cand, s_thr, s_cnt, s_flag, q0, t * RT + wm * 64, wq * NJ * 32, l31, h);
     }
 
     // ---- final: every query's k best keys of this row range -> part ---------------------
     __syncthreads();
+    if ((DIAG & 512) && tid == 0 && (b == 0 || b == 300))
+        printf("wg %d tiles %lld lane-pushes %d compactions %d slow-path wave entries %d\n", b, (long long)(t_end - t_begin), s_flag[1], s_flag[2], s_flag[3]);
     {
-        u64* scratch = reinterpret_cast<u64*>(As) + wave * CAPQ;
-        for (int ql = wave; ql < GT; ql += 4) {
+        u64* scratch = reinterpret_cast<u64*>(As) + wave * CAPQ2;
+        for (int ql = wave; ql < QT; ql += 4) {
             if (q0 + ql >= a.nq) continue;
             const int c = s_cnt[ql];
-            for (int i = lane; i < CAPQ; i += 64) scratch[i] = (i < c) ? cand[(size_t)ql * CAPQ + i] : KEY_EMPTY;
-            bitonic_sort_desc_lds(scratch, CAPQ, lane, 64, SyncWave());
+            const int n2 = pow2_ceil(c > k ? c : k);
+            for (int i = lane; i < n2; i += 64) scratch[i] = (i < c) ? cand[(size_t)ql * CAPQ + i] : KEY_EMPTY;
+            if (!(DIAG & 64)) bitonic_sort_desc_lds(scratch, n2, lane, 64, SyncWave());
             u64* out = a.part + ((size_t)(q0 + ql) * a.S + sp) * k;
             for (int i = lane; i < k; i += 64) out[i] = scratch[i];
             SyncWave()();
@@ -344,68 +361,87 @@ static int env_int_g(const char* name, int dflt) {
 }
 
 bool gemm_topk_supported(const rag_index* h, long long nq, int k) {
-    static const int min_nq = env_int_g("RAG_GEMM_MIN_NQ", 16);
+    static const int min_nq = env_int_g("RAG_GEMM_MIN_NQ", 9);
     return h->kind == RAG_KIND_FLAT && nq >= min_nq && k <= GEMM_MAX_K && (h->ld % GK) == 0 && h->n >= 1;
 }
 
-// (query blocks, padded query blocks, row ranges) for a batch of nq queries
-static void gemm_plan(const rag_index* h, long long nq, int* nqb, int* nqb_pad, int* S) {
+struct GemmPlan {
+    int RT, QT;          // tile shape
+    int nqb, nqb_pad, S;
+    long long ntiles;
+    size_t cand_bytes, part_bytes;
+};
+
+// tile shape, (query blocks, padded query blocks, row ranges) and workspace for a batch of nq queries
+static GemmPlan gemm_plan(const rag_index* h, long long nq, int k) {
     static const int target_wgs = env_int_g("RAG_GEMM_WGS", 512);
-    *nqb = (int)((nq + GT - 1) / GT);
-    *nqb_pad = *nqb > 8 ? ((*nqb + 7) & ~7) : *nqb;
-    long long s = target_wgs / *nqb_pad;
+    static const int force_qt = env_int_g("RAG_GEMM_QT", 0);
+    GemmPlan p;
+    p.QT = force_qt ? force_qt : (nq <= 32 ? 32 : nq <= 64 ? 64 : 128);
+    p.RT = p.QT == 32 ? 256 : 128;
+    p.nqb = (int)((nq + p.QT - 1) / p.QT);
+    p.nqb_pad = p.nqb > 8 ? ((p.nqb + 7) & ~7) : p.nqb;
+    long long s = target_wgs / p.nqb_pad;
     if (s < 1) s = 1;
     // a row range should hold at least 8 tiles, or splitting costs more than it spreads
-    const long long ntiles = (h->n + GT - 1) / GT;
-    const long long max_s = (ntiles + 7) / 8;
+    p.ntiles = (h->n + p.RT - 1) / p.RT;
+    const long long max_s = (p.ntiles + 7) / 8;
     if (s > max_s) s = max_s < 1 ? 1 : max_s;
-    *S = (int)s;
+    p.S = (int)s;
+    p.cand_bytes = (size_t)p.nqb_pad * p.S * p.QT * gemm_capq(p.RT, p.QT) * sizeof(u64);
+    p.part_bytes = (size_t)nq * p.S * k * sizeof(u64);
+    return p;
 }
 
 // bytes of workspace the gemm path needs after the padded queries
 size_t gemm_topk_workspace(const rag_index* h, long long nq, int k) {
-    int nqb, nqb_pad, S;
-    gemm_plan(h, nq, &nqb, &nqb_pad, &S);
-    return (size_t)nqb_pad * S * GT * CAPQ * sizeof(u64) + (size_t)nq * S * k * sizeof(u64);
+    const GemmPlan p = gemm_plan(h, nq, k);
+    return p.cand_bytes + p.part_bytes;
+}
+
+template <int RT, int QT>
+static int launch_gemm(const GemmArgs& a, int grid, int device, hipStream_t s) {
+    const size_t lds = (size_t)(2 * (RT + QT) * GK) * sizeof(float) + QT * 8 + 16;
+    static bool attr_set[64] = {};          // per device: the attribute belongs to the device's code object
+    if (!attr_set[device & 63]) {
+        RAG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_topk_kernel<RT, QT>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[device & 63] = true;
+    }
+    hipLaunchKernelGGL((gemm_topk_kernel<RT, QT>), dim3(grid), dim3(256), lds, s, a);
+    RAG_HIP_CHECK(hipGetLastError());
+    return RAG_OK;
 }
 
 int gemm_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask,
                      float* D, long long* I, hipStream_t s) {
-    static const int use_dma = env_int_g("RAG_GEMM_DMA", 1);
+    const GemmPlan p = gemm_plan(h, nq, k);
     GemmArgs a;
     a.X = h->X;
     a.mask = mask;
     a.n = h->n;
-    a.ntiles = (h->n + GT - 1) / GT;
+    a.ntiles = p.ntiles;
     a.nq = (int)nq;
     a.ld = h->ld;
     a.k = k;
-    gemm_plan(h, nq, &a.nqb, &a.nqb_pad, &a.S);
-    const int grid = a.nqb_pad * a.S;
+    a.nqb = p.nqb;
+    a.nqb_pad = p.nqb_pad;
+    a.S = p.S;
+    const int grid = p.nqb_pad * p.S;
     // workspace: [queries | candidate buffers | partial keys]
     const size_t qbytes = ((size_t)nq * h->ld * sizeof(float) + 255) & ~(size_t)255;
-    const size_t cbytes = (size_t)grid * GT * CAPQ * sizeof(u64);
-    const size_t pbytes = (size_t)nq * a.S * k * sizeof(u64);
-    if (h->ws.bytes < qbytes + cbytes + pbytes)
+    if (h->ws.bytes < qbytes + p.cand_bytes + p.part_bytes)
         return fail(RAG_ERR_INVALID, "internal: workspace not sized for the gemm path");
     a.Q = qbuf;
     a.cand = reinterpret_cast<u64*>(static_cast<char*>(h->ws.ptr) + qbytes);
-    a.part = reinterpret_cast<u64*>(static_cast<char*>(h->ws.ptr) + qbytes + cbytes);
-    const size_t lds = (size_t)(4 * GT * (use_dma ? GK : GLD)) * sizeof(float) + GT * 8 + 16;
-    static bool attr_set = false;
-    if (!attr_set) {
-        const size_t lds_max = (size_t)(4 * GT * GLD) * sizeof(float) + GT * 8 + 16;
-        RAG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_topk_kernel<true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-        RAG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_topk_kernel<false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-        attr_set = true;
-    }
+    a.part = reinterpret_cast<u64*>(static_cast<char*>(h->ws.ptr) + qbytes + p.cand_bytes);
     if (int rc = profile_begin(h, s)) return rc;
-    if (use_dma) hipLaunchKernelGGL(gemm_topk_kernel<true>, dim3(grid), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL(gemm_topk_kernel<false>, dim3(grid), dim3(256), lds, s, a);
-    RAG_HIP_CHECK(hipGetLastError());
-    if (int rc = profile_end(h, s)) return rc;
+    int rc;
+    if (p.QT == 32) rc = launch_gemm<256, 32>(a, grid, h->device, s);
+    else if (p.QT == 64) rc = launch_gemm<128, 64>(a, grid, h->device, s);
+    else rc = launch_gemm<128, 128>(a, grid, h->device, s);
+    if (rc) return rc;
+    if (int rc2 = profile_end(h, s)) return rc2;
     MergeArgs m = {};
     m.keys = a.part;
     m.per_query = (long long)a.S * k;

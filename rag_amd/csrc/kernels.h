@@ -30,6 +30,7 @@ struct ScanArgs {
     int ivf_nprobe;
     int ivf_slices;
     int grid_y;
+    int nq_valid;                 // query slots of a pass that hold real queries (0 = all); the rest repeat the last one
 };
 
 struct MergeArgs {

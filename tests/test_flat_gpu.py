@@ -39,7 +39,8 @@ def test_flat_ip_matches_oracle(n, d):
         D, I = idx.search(Q[:nq], 10)
         assert D.dtype == np.float32 and I.dtype == np.int64 and D.shape == (nq, 10)
         _check(D, I, X, Q[:nq], 10)
-    assert idx.last_path == "scan"
+        if nq <= 8:
+            assert idx.last_path == "scan"
     idx.close()
 
 
@@ -184,6 +185,25 @@ def test_torch_device_path_and_adopt():
     D, I = idx2.search(qt[:1], 5)
     _check(D.cpu().numpy(), I.cpu().numpy() - 1_000_000, X, Q[:1], 5)
     idx2.close()
+
+
+@pytest.mark.parametrize("d", [768, 100])
+def test_every_small_batch_size(d):
+    """Batches that are not a power of two run one padded pass (3 -> 4 slots, 5..7 -> 8);
+    d = 100 has no MFMA path, so 13 queries are two scan passes, the second one padded."""
+    from rag_amd import DeviceIndex
+    rng = np.random.default_rng(31 + d)
+    n, k = 50_000, 10
+    X = _unit(rng, n, d)
+    Q = _unit(rng, 13, d)
+    idx = DeviceIndex(d, metric="ip")
+    idx.add(X)
+    for nq in (1, 2, 3, 4, 5, 6, 7, 8, 13):
+        D, I = idx.search(Q[:nq], k)
+        if nq <= 8 or d == 100:
+            assert idx.last_path == "scan"
+        _check(D, I, X, Q[:nq], k)
+    idx.close()
 
 
 def test_searches_on_different_streams_are_ordered():

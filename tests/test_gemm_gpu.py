@@ -25,7 +25,10 @@ def _check(D, I, X, Q, k, **kw):
 @pytest.mark.parametrize("n,d,nq,k", [
     (40_000, 768, 256, 10), (33_333, 384, 100, 10), (20_000, 1024, 129, 10), (70_001, 128, 1000, 10),
     (5_000, 64, 16, 1), (9_000, 256, 300, 64), (100, 32, 40, 10), (127, 512, 64, 10), (128, 96, 17, 5),
-    (3, 768, 20, 10), (50_000, 768, 2048, 10)])
+    (3, 768, 20, 10), (50_000, 768, 2048, 10),
+    # the narrow tile shapes (<= 32 and <= 64 queries per block, 256-row tiles)
+    (40_000, 768, 9, 10), (40_000, 768, 32, 10), (40_001, 768, 33, 10), (25_000, 1024, 64, 64),
+    (300, 64, 12, 10), (1_000, 256, 48, 3), (255, 384, 31, 10), (257, 384, 50, 64)])
 def test_gemm_matches_oracle(n, d, nq, k):
     from rag_amd import DeviceIndex
     rng = np.random.default_rng(n * 7 + d + nq)
@@ -39,12 +42,14 @@ def test_gemm_matches_oracle(n, d, nq, k):
     idx.close()
 
 
-def test_gemm_adversarial_order_duplicates_and_mask():
+@pytest.mark.parametrize("nq", [20, 64, 130])
+def test_gemm_adversarial_order_duplicates_and_mask(nq):
     """Rows sorted by increasing score for one query make every row a candidate
-    (the buffers must compact, never overflow); duplicate rows tie exactly."""
+    (the buffers must compact, never overflow); duplicate rows tie exactly.
+    One case per tile shape."""
     from rag_amd import DeviceIndex
     rng = np.random.default_rng(23)
-    n, d, nq = 30_000, 128, 64
+    n, d = 30_000, 128
     X = _unit(rng, n, d)
     Q = _unit(rng, nq, d)
     order = np.argsort(X @ Q[0])                 # ascending for query 0
