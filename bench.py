@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--big-batch", type=int, default=4096)
     ap.add_argument("--big-steps", type=int, default=0, help="batch-4096 steps (0: min(steps, 5))")
     ap.add_argument("--no-big", action="store_true", help="skip the batch-4096 leg")
+    ap.add_argument("--mid-batch", type=int, default=32, help="a serving-sized batch reported beside the two headline ones (0: skip)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-rows", type=int, default=1_000_000)
     return ap.parse_args()
@@ -198,33 +199,37 @@ def main():
              "kernel_ms": k_avg_ms, "launches": launches,
              "algorithmic_bytes_per_launch": (hi - lo) * bytes_per_row}
 
-    # ---------------- batch 4096 ----------------
-    big = None
-    if not args.no_big:
-        B = args.big_batch
-        nbig = args.big_steps or min(args.steps, 5)
-
+    # ---------------- batch 4096 (and a serving-sized batch) ----------------
+    def batch_leg(B, nsteps):
         def stepb(i):
             search(Q[:B], k)
 
         stepb(0)
         torch.cuda.synchronize(device)
         index.profile_read(reset=True)
-        dtb = timed_steps(torch, dist, world, stepb, 0, nbig, device)
+        dtb = timed_steps(torch, dist, world, stepb, 0, nsteps, device)
         kmsb, launchesb = index.profile_read(reset=True)
         pathb = index.last_path
         flops = 2.0 * B * (hi - lo) * args.dim           # per step on this rank
-        kb_ms = kmsb / max(nbig, 1)                       # dominant-kernel time per step
+        kb_ms = kmsb / max(nsteps, 1)                     # dominant-kernel time per step
         ach_tf = flops / (kb_ms * 1e-3) / 1e12 if kmsb > 0 else 0.0
-        big = {"value": B * nbig / dtb, "unit": "queries/sec", "batch": B, "steps": nbig,
-               "ms_per_step": dtb / nbig * 1e3, "path": pathb,
-               "roofline": {"bound": "mfma" if pathb == "gemm" else "hbm", "achieved": ach_tf,
-                            "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": ach_tf / FP32_MFMA_PEAK_TFLOPS,
-                            "traffic": measured_traffic("gemm_topk_kernel", args.rows, args.dim, world)
-                            if B == 4096 else None,
-                            "kernel_ms_per_step": kb_ms, "launches": launchesb,
-                            "algorithmic_flops_per_step": flops}}
+        ach_gbs = (hi - lo) * bytes_per_row / (kb_ms * 1e-3) / 1e9 if kmsb > 0 else 0.0
+        return {"value": B * nsteps / dtb, "unit": "queries/sec", "batch": B, "steps": nsteps,
+                "ms_per_step": dtb / nsteps * 1e3, "path": pathb,
+                "roofline": {"bound": "mfma", "achieved": ach_tf,
+                             "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": ach_tf / FP32_MFMA_PEAK_TFLOPS,
+                             "traffic": measured_traffic("gemm_topk_kernel", args.rows, args.dim, world)
+                             if B == 4096 else None,
+                             "kernel_ms_per_step": kb_ms, "launches": launchesb,
+                             "algorithmic_flops_per_step": flops,
+                             "corpus_GBps": ach_gbs, "corpus_frac_of_hbm_peak": ach_gbs / HBM_PEAK_GBS}}
+
+    big = mid = None
+    if not args.no_big:
+        big = batch_leg(args.big_batch, args.big_steps or min(args.steps, 5))
+    if args.mid_batch > 0:
+        mid = batch_leg(min(args.mid_batch, args.big_batch), min(args.steps, 20))
     index.profile(False)
 
     cpu = None
@@ -248,6 +253,8 @@ def main():
         }
         if big is not None:
             out["batch_%d" % args.big_batch] = big
+        if mid is not None:
+            out["batch_%d" % mid["batch"]] = mid
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

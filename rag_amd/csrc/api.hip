@@ -186,8 +186,10 @@ static int scan_blocks(const rag_index* h) {
     static const int max_blocks = env_int("RAG_SCAN_BLOCKS", 512);
     const int tile = scan_rows_per_tile(h->ld / 4);
     const long long ntiles = (h->n + tile - 1) / tile;
-    // at least ~64 tiles per wave before adding another wave; at most 4 blocks per CU
-    long long waves = (ntiles + 63) / 64;
+    // a wave should have a few tiles to walk before another wave (and its partial list, which
+    // the merge has to read) is worth adding; at most 2 blocks per CU
+    static const int min_tiles = std::max(1, env_int("RAG_SCAN_MIN_TILES", 16));
+    long long waves = (ntiles + min_tiles - 1) / min_tiles;
     long long blocks = (waves + 3) / 4;
     if (blocks < 1) blocks = 1;
     if (blocks > max_blocks) blocks = max_blocks;
@@ -207,7 +209,8 @@ static int flat_scan_search(rag_index* h, long long nq, const float* qbuf, int k
     // (the caller placed qbuf at ws.ptr; keep it there)
     if (int rc = h->ws.ensure(qbytes + pbytes)) return rc;
     u64* part = reinterpret_cast<u64*>(static_cast<char*>(h->ws.ptr) + qbytes);
-    const int cap = merge_cap((long long)waves * k, k);
+    const long long lists = (long long)blocks * scan_lists_per_block(k);
+    const int cap = merge_cap(lists * k, k);
     long long q0 = 0;
     while (q0 < nq) {
         // queries per pass: 8, or the next power of two above what is left (a pass costs one
@@ -242,7 +245,7 @@ static int flat_scan_search(rag_index* h, long long nq, const float* qbuf, int k
         if (int rc = profile_end(h, s)) return rc;
         MergeArgs m;
         m.keys = part;
-        m.per_query = (long long)waves * k;
+        m.per_query = lists * k;
         m.k = k;
         m.cap = cap;
         m.min_score = min_score;
@@ -658,7 +661,7 @@ int rag_index_search_segments(rag_index_t* h, int64_t nq, const float* q, int64_
     if (int rc = profile_end(h, s)) return rc;
     MergeArgs m = {};
     m.keys = part;
-    m.per_query = (long long)waves * k;
+    m.per_query = (long long)slices * scan_lists_per_block(k) * k;          // lists of one (query, segment)
     m.k = k;
     m.cap = merge_cap(m.per_query, k);
     m.min_score = min_score;

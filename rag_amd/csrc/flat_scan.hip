@@ -241,15 +241,52 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(ScanArgs a) {
 
     // ---- publish this wave's k keys per query -----------------------------------
     if constexpr (!BIGK) {
+        // the block's four lists are merged here (three bitonic merges in registers), so the
+        // merge kernel reads one list per block
+        const size_t qbytes = Q_IN_REGS ? 0 : (((size_t)NQ * d4 * 16 + 15) & ~(size_t)15);
+        u64* comb = reinterpret_cast<u64*>(smem + qbytes);          // [NQ][3][64]
+        if (wib > 0) {
 #pragma unroll
-        for (int qi = 0; qi < NQ; ++qi)
-            if (lane < k) a.part[(((size_t)blockIdx.y * NQ + qi) * nwaves + w) * k + lane] = list[qi];
+            for (int qi = 0; qi < NQ; ++qi) comb[(qi * 3 + wib - 1) * 64 + lane] = list[qi];
+        }
+        __syncthreads();
+        if (wib == 0) {
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi) {
+                u64 best = list[qi];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) best = wave_merge_top64(best, comb[(qi * 3 + j) * 64 + lane], lane);
+                if (lane < k) a.part[(((size_t)blockIdx.y * NQ + qi) * gridDim.x + blockIdx.x) * k + lane] = best;
+            }
+        }
     } else {
         // pad with empties, sort, write the first k
         for (int i = cnt + lane; i < capw; i += 64) wbuf[i] = KEY_EMPTY;
         bitonic_sort_desc_lds(wbuf, capw, lane, 64, SyncWave());
         for (int i = lane; i < k; i += 64) a.part[((size_t)blockIdx.y * nwaves + w) * k + i] = wbuf[i];
     }
+}
+
+// final step of every merge: key -> (score, id) with the min_score cut and (-FLT_MAX, -1) padding
+__device__ __forceinline__ void finalise_hit(const MergeArgs& a, long long q, int j, u64 key) {
+    const int k = a.k;
+    float s = -3.402823466e+38f;
+    long long id = -1;
+    if (key != KEY_EMPTY) {
+        const float sc = key_score(key);
+        if (sc >= a.min_score) {
+            const uint32_t slot = key_row(key);
+            s = sc;
+            if (a.slot_ids) {   // merge of finished lists: slot = list*k + rank
+                const uint32_t g = slot / (uint32_t)k, r = slot % (uint32_t)k;
+                id = a.slot_ids[(size_t)g * a.slot_stride + (size_t)q * k + r];
+            }
+            else if (a.row_ids) id = a.row_ids[slot];
+            else id = a.id_base + (long long)slot;
+        }
+    }
+    a.D[(size_t)q * k + j] = s;
+    a.I[(size_t)q * k + j] = id;
 }
 
 // ---------------------------------------------------------------------------
@@ -265,8 +302,43 @@ __global__ __launch_bounds__(1024) void merge_keys_kernel(MergeArgs a) {
     const int k = a.k;
     u64* s_thr = buf + cap;                               // [cap]   current k-th key
     int* s_cnt = reinterpret_cast<int*>(buf + cap + 1);   // [cap+1] keys in buf
+    u64* cand = buf + cap + 2;                            // [MERGE_FAST_CAP] fast path only
     const long long q = blockIdx.x;
     const u64* in = a.keys + (size_t)q * a.per_query;
+
+    // ---- fast path: the input is P descending runs of k keys.  The k-th largest run head is a
+    // lower bound of the answer's k-th key (k different keys reach it), and only keys at or above
+    // it matter: each thread walks its runs from the head and stops at the first key below.
+    const long long P = a.per_query / k;
+    if (a.fast_cap > 0 && P >= k && P <= cap && P * k == a.per_query) {
+        const int n2 = pow2_ceil((int)P);
+        for (int i = tid; i < n2; i += 1024) buf[i] = i < P ? in[(size_t)i * k] : KEY_EMPTY;
+        if (tid == 0) *s_cnt = 0;
+        bitonic_sort_desc_lds(buf, n2, tid, 1024, SyncBlock());
+        const u64 bound = buf[k - 1];
+        __syncthreads();
+        if (bound != KEY_EMPTY) {
+            for (long long p = tid; p < P; p += 1024) {
+                for (int j = 0; j < k; ++j) {
+                    const u64 key = in[(size_t)p * k + j];
+                    if (key < bound) break;
+                    const int pos = atomicAdd(s_cnt, 1);
+                    if (pos < a.fast_cap) cand[pos] = key;
+                }
+            }
+            __syncthreads();
+            const int c = *s_cnt;
+            if (c <= a.fast_cap) {
+                const int c2 = pow2_ceil(c);
+                for (int i = c + tid; i < c2; i += 1024) cand[i] = KEY_EMPTY;
+                bitonic_sort_desc_lds(cand, c2, tid, 1024, SyncBlock());
+                for (int j = tid; j < k; j += 1024) finalise_hit(a, q, j, cand[j]);     // c >= k here
+                return;
+            }
+        }
+        __syncthreads();      // too many keys tie near the bound: stream everything instead
+    }
+
     for (int i = tid; i < cap; i += 1024) buf[i] = KEY_EMPTY;
     if (tid == 0) { *s_cnt = 0; *s_thr = KEY_EMPTY; }
     __syncthreads();
@@ -292,27 +364,56 @@ __global__ __launch_bounds__(1024) void merge_keys_kernel(MergeArgs a) {
         __syncthreads();
     }
     bitonic_sort_desc_lds(buf, cap, tid, 1024, SyncBlock());
-    // ---- finalise: keys -> (score, id), threshold, padding ------------------------
-    for (int j = tid; j < k; j += 1024) {
-        const u64 key = buf[j];
-        float s = -3.402823466e+38f;
-        long long id = -1;
-        if (key != KEY_EMPTY) {
-            const float sc = key_score(key);
-            if (sc >= a.min_score) {
-                const uint32_t slot = key_row(key);
-                s = sc;
-                if (a.slot_ids) {   // merge of finished lists: slot = list*k + rank
-                    const uint32_t g = slot / (uint32_t)k, j = slot % (uint32_t)k;
-                    id = a.slot_ids[(size_t)g * a.slot_stride + (size_t)q * k + j];
+    for (int j = tid; j < k; j += 1024) finalise_hit(a, q, j, buf[j]);
+}
+
+// The same merge for k <= 64 in registers: every wave streams its share of the keys through a
+// sorted list held one key per lane.  Of each 64 keys only those that beat the wave's k-th are
+// looked at: a few are inserted one by one, many are sorted across the lanes and merged in one
+// bitonic step.  The waves' lists are then merged pairwise (tree over LDS).
+__global__ __launch_bounds__(1024) void merge_keys_small_kernel(MergeArgs a) {
+    __shared__ u64 s_lists[16 * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nw = blockDim.x >> 6;
+    const int k = a.k;
+    const long long q = blockIdx.x;
+    const u64* in = a.keys + (size_t)q * a.per_query;
+    u64 list = KEY_EMPTY, thr = KEY_EMPTY;
+    for (long long base = (long long)wave * 64; base < a.per_query; base += (long long)nw * 64) {
+        const long long i = base + lane;
+        const u64 key = i < a.per_query ? in[i] : KEY_EMPTY;
+        const bool cand = key > thr;
+        u64 m = __ballot(cand);
+        if (m == 0) continue;
+        if (__popcll(m) <= 6) {
+            while (m) {
+                const int j = __builtin_ctzll(m);
+                m &= m - 1;
+                const u64 kj = readlane_u64(key, j);
+                if (kj > thr) {
+                    wave_list_insert(list, kj, lane);
+                    thr = readlane_u64(list, k - 1);
                 }
-                else if (a.row_ids) id = a.row_ids[slot];
-                else id = a.id_base + (long long)slot;
             }
+        } else {
+            // every producer writes descending runs of k keys, so with k = 64 the 64 keys a wave
+            // reads are one run, and cutting its tail at the threshold keeps it descending
+            u64 run = cand ? key : KEY_EMPTY;
+            if (k != 64) run = wave_sort_desc(run, lane);
+            list = wave_merge_top64(list, run, lane);
+            thr = readlane_u64(list, k - 1);
         }
-        a.D[(size_t)q * k + j] = s;
-        a.I[(size_t)q * k + j] = id;
     }
+    s_lists[wave * 64 + lane] = list;
+    for (int stride = 1; stride < nw; stride <<= 1) {
+        __syncthreads();
+        if ((wave & (2 * stride - 1)) == 0 && wave + stride < nw) {
+            list = wave_merge_top64(list, s_lists[(wave + stride) * 64 + lane], lane);
+            s_lists[wave * 64 + lane] = list;
+        }
+    }
+    if (wave == 0 && lane < k) finalise_hit(a, q, lane, list);
 }
 
 // (D, I) result lists -> keys whose "row" is the slot (list*k + rank) in the
@@ -412,6 +513,9 @@ static hipError_t launch_scan_nq(const ScanArgs& a, int blocks, size_t lds, hipS
     return launch_scan_t<64, 0, 4, NQ, BIGK>(a, blocks, lds, s);
 }
 
+// partial lists a scan block leaves per query: one (merged in the block) for k <= 64, one per wave above
+int scan_lists_per_block(int k) { return k > 64 ? 4 : 1; }
+
 int scan_rows_per_tile(int d4) {
     if (d4 == 256) return 2;
     if (d4 == 96 || d4 == 32) return 8;
@@ -433,6 +537,7 @@ hipError_t launch_flat_scan(ScanArgs a, int nq, int blocks, hipStream_t s) {
     // queries live in registers only for NQ == 1 with a compile-time chunk count
     const bool q_in_regs = (nq == 1) && (a.d4 == 192 || a.d4 == 256 || a.d4 == 96 || a.d4 == 128 || a.d4 == 64 || a.d4 == 32 || a.d4 <= 16);
     size_t lds = q_in_regs ? 0 : (((size_t)nq * a.d4 * 16 + 15) & ~(size_t)15);
+    if (!bigk) lds += (size_t)nq * 3 * 64 * sizeof(u64);          // lists of waves 1..3, merged by wave 0
     if (bigk) {
         a.capw = 2 * pow2_ceil(a.k);
         lds += (size_t)4 * a.capw * sizeof(u64);
@@ -448,12 +553,23 @@ hipError_t launch_flat_scan(ScanArgs a, int nq, int blocks, hipStream_t s) {
 }
 
 hipError_t launch_merge_keys(const MergeArgs& a, long long nq, hipStream_t s) {
-    const size_t lds = (size_t)(a.cap + 2) * sizeof(u64);
+    static const bool small_ok = !(getenv("RAG_MERGE_SORT") && atoi(getenv("RAG_MERGE_SORT")) != 0);
+    if (a.k <= 64 && small_ok) {
+        long long waves = (a.per_query + 511) / 512;           // ~8 ballots of 64 keys per wave
+        waves = waves < 1 ? 1 : waves > 16 ? 16 : waves;
+        hipLaunchKernelGGL(merge_keys_small_kernel, dim3((unsigned)nq), dim3((unsigned)waves * 64), 0, s, a);
+        return hipGetLastError();
+    }
+    MergeArgs b = a;
+    static const bool fast_ok = !(getenv("RAG_MERGE_FAST") && atoi(getenv("RAG_MERGE_FAST")) == 0);
+    const long long runs = a.per_query / a.k;
+    b.fast_cap = (fast_ok && runs >= a.k && runs <= a.cap) ? 4096 : 0;
+    const size_t lds = (size_t)(a.cap + 2 + b.fast_cap) * sizeof(u64);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(merge_keys_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(merge_keys_kernel, dim3((unsigned)nq), dim3(1024), lds, s, a);
+    hipLaunchKernelGGL(merge_keys_kernel, dim3((unsigned)nq), dim3(1024), lds, s, b);
     return hipGetLastError();
 }
 

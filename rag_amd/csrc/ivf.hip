@@ -189,7 +189,6 @@ int ivf_search_device(rag_index* h, long long nq, const float* qbuf, int k, floa
     // --- list scan ------------------------------------------------------------------------------
     const long long slices = ivf_slices(h, nq, nprobe);
     const int gx = (int)(nprobe * slices);
-    const int waves = gx * 4;
     const size_t qbytes = ((size_t)nq * h->ld * sizeof(float) + 255) & ~(size_t)255;
     const long long qchunk = IVF_QCHUNK;
     if (h->ws.bytes < qbytes + ivf_search_workspace(h, nq, k, nprobe))
@@ -219,7 +218,7 @@ int ivf_search_device(rag_index* h, long long nq, const float* qbuf, int k, floa
         if (int rc = profile_end(h, s)) return rc;
         MergeArgs m;
         m.keys = part;
-        m.per_query = (long long)waves * k;
+        m.per_query = (long long)gx * scan_lists_per_block(k) * k;
         m.k = k;
         m.cap = merge_cap(m.per_query, k);
         m.min_score = min_score;

@@ -34,10 +34,11 @@ struct ScanArgs {
 };
 
 struct MergeArgs {
-    const u64* keys;             // [nq][per_query]
+    const u64* keys;             // [nq][per_query], descending runs of k keys (one per producer)
     long long per_query;
     int k;
     int cap;                     // LDS buffer capacity (power of two, >= 2k, >= 2048)
+    int fast_cap;                // set by the launcher: candidate slots of the run-head fast path (0 = off)
     float min_score;
     const long long* row_ids;    // nullptr: id = id_base + row
     long long id_base;
@@ -48,6 +49,7 @@ struct MergeArgs {
 };
 
 int scan_rows_per_tile(int d4);
+int scan_lists_per_block(int k);
 int scan_lanes_per_row(int d4);
 hipError_t launch_flat_scan(ScanArgs a, int nq, int blocks, hipStream_t s);
 hipError_t launch_merge_keys(const MergeArgs& a, long long nq, hipStream_t s);

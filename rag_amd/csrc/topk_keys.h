@@ -104,6 +104,48 @@ __device__ __forceinline__ void wave_list_insert(u64& list, u64 key, int lane) {
 }
 
 // ---------------------------------------------------------------------------
+// One key per lane: sorting and merging across the 64 lanes of a wave.
+__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int mask) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, mask, 64);
+    const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), mask, 64);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, 64);
+    const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64);
+    return ((u64)hi << 32) | lo;
+}
+// a bitonic sequence over the lanes -> descending order (lane 0 the largest)
+__device__ __forceinline__ u64 wave_bitonic_merge_desc(u64 v, int lane) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        const u64 o = shfl_xor_u64(v, s);
+        const bool lower = (lane & s) == 0;
+        v = (lower == (v > o)) ? v : o;         // lower lane keeps the larger key
+    }
+    return v;
+}
+// any order -> descending order
+__device__ __forceinline__ u64 wave_sort_desc(u64 v, int lane) {
+#pragma unroll
+    for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+        for (int s = size >> 1; s > 0; s >>= 1) {
+            const u64 o = shfl_xor_u64(v, s);
+            const bool desc = (size == 64) || ((lane & size) == 0);
+            const bool lower = (lane & s) == 0;
+            v = ((lower == desc) == (v > o)) ? v : o;
+        }
+    }
+    return v;
+}
+// the 64 largest of two descending lists, descending
+__device__ __forceinline__ u64 wave_merge_top64(u64 a, u64 b, int lane) {
+    const u64 r = shfl_u64(b, 63 - lane);
+    return wave_bitonic_merge_desc(a > r ? a : r, lane);
+}
+
+// ---------------------------------------------------------------------------
 // Bitonic sort, descending, of n (power of two) keys in LDS by `nthreads`
 // threads that all call it.  SYNC() separates the stages: __syncthreads() for a
 // workgroup-shared array, a wave-local fence for a wave-private one.
