@@ -74,6 +74,39 @@ class CorpusStatsManager:
             logger.error(f"BM25 calculation failed: {e}")
             return sum(1 for t in query_terms if t in document_text.lower()) / len(query_terms)
 
+    def calculate_bm25_scores(self, query_terms: List[str], document_texts: Sequence[Optional[str]],
+                              corpus_stats: Dict[str, Any], k1: float = 1.5, b: float = 0.75) -> List[float]:
+        """``calculate_bm25_score`` (:142-180) for a list of candidate texts at once: every text is
+        tokenised once, then the terms are accumulated in query order with one array operation
+        per term.  The per-document operation order is the scalar one, so the float64 results
+        are bit-identical (a term that does not occur adds exactly 0.0)."""
+        import numpy as np
+        n = len(document_texts)
+        if not query_terms or n == 0:
+            return [0.0] * n
+        avgdl = corpus_stats.get("avg_doc_length", 100)
+        idf = corpus_stats.get("idf", {})
+        dl = np.zeros(n, dtype=np.float64)
+        tf = np.zeros((len(query_terms), n), dtype=np.float64)
+        live = np.zeros(n, dtype=bool)
+        for j, text in enumerate(document_texts):
+            if not text or not text.strip():
+                continue
+            live[j] = True
+            counts = Counter(self.preprocess_query(text))
+            dl[j] = sum(counts.values())
+            for t, term in enumerate(query_terms):
+                tf[t, j] = counts.get(term, 0)
+        denom_len = k1 * (1 - b + b * (dl / avgdl))
+        score = np.zeros(n, dtype=np.float64)
+        for t, term in enumerate(query_terms):
+            f = tf[t]
+            with np.errstate(invalid="ignore", divide="ignore"):
+                part = idf.get(term, 0.5) * ((f * (k1 + 1)) / (f + denom_len))
+            score = score + np.where(f > 0, part, 0.0)
+        score = np.where(live, np.maximum(score, 0.0), 0.0)
+        return score.tolist()
+
     @staticmethod
     def _sigmoid_normalize(score: float, scale: float = 2.0) -> float:
         try:
@@ -113,7 +146,7 @@ class CorpusStatsManager:
         if not terms or not candidate_texts:
             return []
         stats = self.compute_corpus_stats(corpus_texts)
-        raw = [self.calculate_bm25_score(terms, t or "", stats) for t in candidate_texts]
+        raw = self.calculate_bm25_scores(terms, candidate_texts, stats)
         norm = self.normalize_scores(raw, "minmax")
         rows = [(i, n, r) for i, (n, r) in enumerate(zip(norm, raw)) if min_score is None or n >= min_score]
         rows.sort(key=lambda t: t[1], reverse=True)

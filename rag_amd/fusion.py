@@ -117,6 +117,29 @@ def hybrid_fuse(semantic: Sequence[Tuple[str, float]], bm25: Sequence[Tuple[str,
             for i in order]
 
 
+def rerank_blend(original: Sequence[float], rerank: Sequence[float], weight: float = 0.5,
+                 min_rerank_score: Optional[float] = None, top_k: Optional[int] = None):
+    """Score blend and ordering of the reranker stage:
+    vector_db/reranker/base_reranker.py:256-280 (both scores clipped to [0, 1],
+    ``(1-w)*orig + w*rerank``) and vector_db/reranker/huggingface_reranker.py:225-264
+    (results under ``min_rerank_score`` dropped, stable sort by the blend descending,
+    first ``top_k``; ``top_k`` of None or 0 keeps all).  The rerank scores themselves
+    come from a cross-encoder, which is outside this library.
+    Returns (indices into the input in result order, blend per input)."""
+    o = np.clip(np.ascontiguousarray(original, dtype=np.float64), 0.0, 1.0)
+    r_raw = np.ascontiguousarray(rerank, dtype=np.float64)
+    if o.size != r_raw.size:
+        raise ValueError("original and rerank must have the same length")
+    keep = np.arange(o.size) if min_rerank_score is None else np.nonzero(~(r_raw < min_rerank_score))[0]
+    if keep.size == 0:
+        return [], np.zeros(o.size)
+    r = np.clip(r_raw, 0.0, 1.0)
+    order, score = fuse_weighted(o[keep], r[keep], 1 - weight, weight, None, top_k if top_k else keep.size)
+    full = np.zeros(o.size)
+    full[keep] = score
+    return [int(keep[i]) for i in order], full
+
+
 def multi_embedding_fuse(per_doc, limit: int):
     """vector_db/search_manager.py:877-932: per document the best ``score*weight``
     per chunk over the query strategies (strict ``>``: first strategy wins ties),

@@ -123,3 +123,26 @@ def test_mmr_rows_of_index_and_oracle_at_config_size():
         got_host = mmr_select_device(X[I[0]], rel, lam, thr, metric, 10)
         assert got_rows == want and got_host == want, (lam, thr, metric)
     idx.close()
+
+
+def test_rerank_blend_matches_reference_formula():
+    """(1-w)*clip(orig) + w*clip(rerank), threshold on the raw rerank score, stable sort, top_k:
+    bit-exact against the oracle's restatement of base_reranker.py:256-280 and the ordering of
+    huggingface_reranker.py:225-264."""
+    from oracle import fusion as of
+    from rag_amd import fusion
+    rng = np.random.default_rng(77)
+    for n, w, thr, top_k in ((50, 0.5, None, None), (200, 0.3, 0.1, 10), (7, 0.9, 2.0, 3), (64, 0.0, None, 5)):
+        orig = rng.uniform(-0.2, 1.3, n)
+        rr = rng.uniform(-0.5, 1.5, n)
+        rr[::7] = rr[0]                       # ties on the rerank side
+        orig[::7] = orig[0]
+        order, blend = fusion.rerank_blend(orig, rr, w, thr, top_k)
+        kept = [i for i in range(n) if thr is None or not (rr[i] < thr)]
+        want = {i: of.rerank_blend(float(orig[i]), float(rr[i]), w) for i in kept}
+        ref = sorted(kept, key=lambda i: want[i], reverse=True)        # stable, like list.sort(reverse=True)
+        if top_k:
+            ref = ref[:top_k]
+        assert order == ref
+        for i in kept:
+            assert blend[i] == want[i]

@@ -93,3 +93,23 @@ def test_shard_range_covers_rows_once():
         assert spans[0][0] == 0 and spans[-1][1] == n
         for (a, b), (c, d) in zip(spans, spans[1:]):
             assert b == c and a <= b
+
+
+def test_bm25_batch_scores_equal_scalar_scores_bitwise():
+    """The array form of calculate_bm25_score (one pass over the candidate texts) gives the
+    same float64 bits as the per-document loop of the reference (search_manager.py:142-180)."""
+    import random
+    from rag_amd.bm25 import CorpusStatsManager
+    rnd = random.Random(5)
+    vocab = ["alpha", "beta", "gamma", "delta", "vector", "search", "index", "kernel", "the", "and", "gpu", "row"]
+    texts = [" ".join(rnd.choice(vocab) for _ in range(rnd.randint(0, 60))) for _ in range(120)]
+    texts[3] = ""
+    texts[4] = "   "
+    texts[5] = None
+    m = CorpusStatsManager()
+    stats = m.compute_corpus_stats([t for t in texts if t])
+    for query in ("alpha vector search", "gpu gpu kernel unknownterm", "the and", "row"):
+        terms = m.preprocess_query(query)
+        batch = m.calculate_bm25_scores(terms, texts, stats)
+        scalar = [m.calculate_bm25_score(terms, t or "", stats) for t in texts]
+        assert batch == scalar
