@@ -11,7 +11,8 @@
 // the next step's global loads are in flight while the current step computes).
 // Three shapes, chosen by the batch size:
 //      RT x QT     waves (rows x queries)   per wave            used for
-//      128 x 128   2 x 2                    64 x 64, 2x2 MFMA   nq > 64
+//      256 x 256   4 x 2 (8 waves)          64 x 128, 2x4 MFMA  nq >= 1024
+//      128 x 128   2 x 2                    64 x 64, 2x2 MFMA   64 < nq < 1024
 //      128 x 64    2 x 2                    64 x 32, 2x1 MFMA   32 < nq <= 64
 //      256 x 32    4 x 1                    64 x 32, 2x1 MFMA   nq <= 32
 // The narrow shapes spend no matrix-core time on padding queries: a batch of 32
@@ -58,14 +59,15 @@ constexpr int GEMM_MAX_K = 64;
 // more than TRIG keys at the end of a tile; a tile adds at most RT, so it holds TRIG + RT.
 // Narrow shapes see few rows per workgroup (the corpus is split 512 ways for a single query
 // block), so they tighten early and often; the square shape streams long ranges and rarely compacts.
-__host__ __device__ constexpr int gemm_trig(int RT, int QT) { return QT == 128 ? RT : 64; }
+__host__ __device__ constexpr int gemm_trig(int RT, int QT) { return QT >= 128 ? RT : 64; }
 __host__ __device__ constexpr int gemm_capq(int RT, int QT) { return gemm_trig(RT, QT) + RT; }
 
 // Timing-only ablations for diagnostic builds (outputs are wrong when non-zero):
 // bit 0 skip the tile epilogue, bit 1 load global tiles only once, bit 2 barrier only twice,
 // bit 3 walk the accumulators but push nothing, bit 4 stop after the epilogue's ballot,
 // bit 5 no sort inside a compaction, bit 6 no sort in the final pass, bit 7 pushes store nothing,
-// bit 8 pushes skip the LDS counter, bit 9 count and print events of two workgroups.
+// bit 8 pushes skip the LDS counter, bit 9 count and print events of two workgroups,
+// bit 10 every load re-reads the first K step of the first tile (load issue cost without memory latency).
 #ifndef RAG_GEMM_DIAG
 #define RAG_GEMM_DIAG 0
 #endif
@@ -85,9 +87,13 @@ struct GemmArgs {
     int nqb;         // query blocks
     int nqb_pad;     // query blocks rounded up for the XCD-friendly decode
     int S;           // row ranges
+    int gq;          // placement: query-block groups across the 8 XCDs (0: plain b % nqb_pad decode)
 };
 
 // rare path of the tile epilogue, kept out of line so that the call sites stay small
+#ifndef RAG_GEMM_SCHED
+#define RAG_GEMM_SCHED 1
+#endif
 #ifndef RAG_GEMM_NARROW_AUX
 #define RAG_GEMM_NARROW_AUX 2
 #endif
@@ -107,10 +113,10 @@ __device__ RAG_GEMM_PUSH_ATTR void push_candidate(const GemmArgs& a, u64* cand, 
 }
 
 // one wave per query: sort the candidate buffer of every query that could overflow on the next tile
-template <int RT, int QT>
+template <int RT, int QT, int NW>
 __device__ __forceinline__ void compact_queries(u64* scratch, u64* cand, int* s_cnt, float* s_thr, int k, int wave, int lane) {
     constexpr int CAPQ = gemm_capq(RT, QT);
-    for (int ql = wave; ql < QT; ql += 4) {
+    for (int ql = wave; ql < QT; ql += NW) {
         const int c = s_cnt[ql];
         if (c <= gemm_trig(RT, QT)) continue;            // wave-uniform
         const int n2 = pow2_ceil(c > k ? c : k);
@@ -164,22 +170,23 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f16v (&acc)[2][
     }
 }
 
-template <int RT, int QT>
-__global__ __launch_bounds__(256, 2) void gemm_topk_kernel(GemmArgs a) {
+template <int RT, int QT, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(GemmArgs a) {
+    constexpr int NT = NW * 64;              // threads
     constexpr int WM = RT / 64;              // waves along the corpus rows
-    constexpr int WQ = 4 / WM;               // waves along the queries
+    constexpr int WQ = NW / WM;              // waves along the queries
     constexpr int NJ = QT / WQ / 32;         // 32-query MFMA columns per wave
     constexpr int CAPQ = gemm_capq(RT, QT);
     constexpr int CAPQ2 = CAPQ <= 256 ? 256 : 512;      // sort size bound (power of two)
-    constexpr int APW = RT / 32;             // 1-KiB DMA pieces (8 rows x 128 B) per wave and K step, corpus
-    constexpr int BPW = QT / 32;             //   ... queries
+    constexpr int APW = RT / (8 * NW);       // 1-KiB DMA pieces (8 rows x 128 B) per wave and K step, corpus
+    constexpr int BPW = QT / (8 * NW);       //   ... queries
     constexpr int TILEA = RT * GK;           // floats per corpus stage
     constexpr int TILEB = QT * GK;
     // cache policy of the corpus loads: a single query block reads every row once (non-temporal,
     // bit 1); with many query blocks the rows are re-read by other workgroups and should stay cached
-    constexpr int A_AUX = (QT == 128) ? 0 : RAG_GEMM_NARROW_AUX;
-    static_assert(WM * WQ == 4 && NJ >= 1 && WM * 64 == RT && WQ * NJ * 32 == QT, "tile shape");
-    static_assert(4 * CAPQ2 * 8 <= TILEA * 4, "compaction scratch must fit in one idle corpus stage");
+    constexpr int A_AUX = (QT >= 128) ? 0 : RAG_GEMM_NARROW_AUX;
+    static_assert(WM * WQ == NW && NJ >= 1 && WM * 64 == RT && WQ * NJ * 32 == QT && APW >= 1 && BPW >= 1, "tile shape");
+    static_assert(NW * CAPQ2 * 8 <= TILEA * 4, "compaction scratch must fit in one idle corpus stage");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* As = reinterpret_cast<float*>(smem);                       // [2][TILEA] corpus rows
     float* Bs = As + 2 * TILEA;                                        // [2][TILEB] queries
@@ -196,8 +203,18 @@ __global__ __launch_bounds__(256, 2) void gemm_topk_kernel(GemmArgs a) {
     const int h = lane >> 5;
 
     const int b = blockIdx.x;
-    const int qb = b % a.nqb_pad;
-    const int sp = b / a.nqb_pad;
+    int qb, sp;
+    if (a.gq > 0) {
+        // XCD x = b % 8 owns query-block group x % gq and row-range group x / gq; inside the XCD
+        // consecutive workgroups take different query blocks of the same row range
+        const int xcd = b & 7, j = b >> 3;
+        const int m = a.nqb_pad / a.gq, r = a.S / (8 / a.gq);
+        qb = (xcd % a.gq) * m + (j % m);
+        sp = (xcd / a.gq) * r + (j / m);
+    } else {
+        qb = b % a.nqb_pad;
+        sp = b / a.nqb_pad;
+    }
     if (qb >= a.nqb) return;
     const int q0 = qb * QT;
     const int k = a.k;
@@ -206,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void gemm_topk_kernel(GemmArgs a) {
     const long long t_end = a.ntiles * (sp + 1) / a.S;
     u64* cand = a.cand + (size_t)b * QT * CAPQ;
 
-    for (int i = tid; i < QT; i += 256) { s_thr[i] = -INFINITY; s_cnt[i] = 0; }
+    for (int i = tid; i < QT; i += NT) { s_thr[i] = -INFINITY; s_cnt[i] = 0; }
     if (tid == 0) { *s_flag = 0; if (DIAG & 512) { s_flag[1] = 0; s_flag[2] = 0; s_flag[3] = 0; } }
     __syncthreads();
 
@@ -278,24 +295,29 @@ __global__ __launch_bounds__(256, 2) void gemm_topk_kernel(GemmArgs a) {
             // a candidate buffer filled up during the previous tile's epilogue: every wave has
             // passed the barrier above, so the flag is stable and stage buf^1 is idle
             if (kt == 0 && *s_flag != 0) {
-                compact_queries<RT, QT>(reinterpret_cast<u64*>(As + (buf ^ 1) * TILEA) + wave * CAPQ2, cand, s_cnt, s_thr, k, wave, lane);
+                compact_queries<RT, QT, NW>(reinterpret_cast<u64*>(As + (buf ^ 1) * TILEA) + wave * CAPQ2, cand, s_cnt, s_thr, k, wave, lane);
                 __syncthreads();
                 if (tid == 0) *s_flag = 0;
                 if ((DIAG & 512) && tid == 0) s_flag[2] += 1;
             }
             if (!(DIAG & 2) || (t == t_begin && kt == 0)) {
-                if (kt + 1 < KT) issue_load(kt + 1, buf ^ 1);
+                if (DIAG & 1024) issue_load(0, buf ^ 1);       // same instructions, cache-resident source
+                else if (kt + 1 < KT) issue_load(kt + 1, buf ^ 1);
                 else if (t + 1 < t_end) { set_tile(t + 1); issue_load(0, buf ^ 1); }
             }
             const float* Ab = As + buf * TILEA + (wm * 64) * GK;
             const float* Bb = Bs + buf * TILEB + (wq * NJ * 32) * GK;
-            // fragments of k block kb+1 are requested while the MFMAs of block kb issue: one
-            // ds_read_b128 in front of every few MFMAs (two register sets, kb parity)
+            // fragments of k block kb+1 are requested while the MFMAs of block kb issue (two
+            // register sets, kb parity).  Issue order, fixed with sched_group_barrier: the reads of
+            // block 0, then per block [2 MFMAs, 1 read] until the next block's reads are out, then
+            // the rest of the block's MFMAs -- every read has most of a block to land.
+            constexpr int READS = 2 + NJ, MFMAS = 8 * NJ;
             f4 fa[2][2], fb[2][NJ];
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) fa[0][mi] = *reinterpret_cast<const f4*>(Ab + mi * 32 * GK + foff[0]);
 #pragma unroll
             for (int nj = 0; nj < NJ; ++nj) fb[0][nj] = *reinterpret_cast<const f4*>(Bb + nj * 32 * GK + foff[0]);
+            if (RAG_GEMM_SCHED == 1) __builtin_amdgcn_sched_group_barrier(0x100, READS, 0);
 #pragma unroll
             for (int kb = 0; kb < GK / 8; ++kb) {
                 const int cur = kb & 1, nxt = cur ^ 1;
@@ -312,8 +334,18 @@ __global__ __launch_bounds__(256, 2) void gemm_topk_kernel(GemmArgs a) {
 #pragma unroll
                         for (int nj = 0; nj < NJ; ++nj)
                             acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][mi][s], fb[cur][nj][s], acc[mi][nj], 0, 0, 0);
-                if (kb + 1 < GK / 8) {
-                    constexpr int READS = 2 + NJ, MFMAS = 8 * NJ;
+                if (RAG_GEMM_SCHED == 1) {
+                    if (kb + 1 < GK / 8) {
+#pragma unroll
+                        for (int j = 0; j < READS; ++j) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x008, MFMAS - 2 * READS, 0);
+                    } else {
+                        __builtin_amdgcn_sched_group_barrier(0x008, MFMAS, 0);
+                    }
+                } else if (kb + 1 < GK / 8) {
 #pragma unroll
                     for (int j = 0; j < READS; ++j) {
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);               // 1 DS read
@@ -342,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void gemm_topk_kernel(GemmArgs a) {
         printf("wg %d tiles %lld lane-pushes %d compactions %d slow-path wave entries %d\n", b, (long long)(t_end - t_begin), s_flag[1], s_flag[2], s_flag[3]);
     {
         u64* scratch = reinterpret_cast<u64*>(As) + wave * CAPQ2;
-        for (int ql = wave; ql < QT; ql += 4) {
+        for (int ql = wave; ql < QT; ql += NW) {
             if (q0 + ql >= a.nq) continue;
             const int c = s_cnt[ql];
             const int n2 = pow2_ceil(c > k ? c : k);
@@ -366,19 +398,22 @@ bool gemm_topk_supported(const rag_index* h, long long nq, int k) {
 }
 
 struct GemmPlan {
-    int RT, QT;          // tile shape
-    int nqb, nqb_pad, S;
+    int RT, QT, NW;      // tile shape, waves per workgroup
+    int nqb, nqb_pad, S, gq;
     long long ntiles;
     size_t cand_bytes, part_bytes;
 };
 
 // tile shape, (query blocks, padded query blocks, row ranges) and workspace for a batch of nq queries
 static GemmPlan gemm_plan(const rag_index* h, long long nq, int k) {
-    static const int target_wgs = env_int_g("RAG_GEMM_WGS", 512);
+    static const int target_wgs_env = env_int_g("RAG_GEMM_WGS", 0);
     static const int force_qt = env_int_g("RAG_GEMM_QT", 0);
+    static const int big_min_nq = env_int_g("RAG_GEMM_BIG_MIN_NQ", 1024);
     GemmPlan p;
-    p.QT = force_qt ? force_qt : (nq <= 32 ? 32 : nq <= 64 ? 64 : 128);
-    p.RT = p.QT == 32 ? 256 : 128;
+    p.QT = force_qt ? force_qt : (nq <= 32 ? 32 : nq <= 64 ? 64 : nq < big_min_nq ? 128 : 256);
+    p.RT = (p.QT == 32 || p.QT == 256) ? 256 : 128;
+    p.NW = p.QT == 256 ? 8 : 4;
+    const int target_wgs = target_wgs_env > 0 ? target_wgs_env : (p.NW == 8 ? 256 : 512);
     p.nqb = (int)((nq + p.QT - 1) / p.QT);
     p.nqb_pad = p.nqb > 8 ? ((p.nqb + 7) & ~7) : p.nqb;
     long long s = target_wgs / p.nqb_pad;
@@ -388,6 +423,14 @@ static GemmPlan gemm_plan(const rag_index* h, long long nq, int k) {
     const long long max_s = (p.ntiles + 7) / 8;
     if (s > max_s) s = max_s < 1 ? 1 : max_s;
     p.S = (int)s;
+    // placement over the XCDs: the widest split of the query blocks that the counts allow
+    static const int gq_env = env_int_g("RAG_GEMM_GQ", -1);
+    p.gq = 0;
+    for (int gq = (gq_env >= 0 ? gq_env : 8); gq >= 1; gq >>= 1) {
+        if (p.nqb_pad % gq == 0 && p.S % (8 / gq) == 0 && ((long long)p.nqb_pad * p.S) % 8 == 0) { p.gq = gq; break; }
+        if (gq_env >= 0) break;
+    }
+    if (gq_env == 0) p.gq = 0;
     p.cand_bytes = (size_t)p.nqb_pad * p.S * p.QT * gemm_capq(p.RT, p.QT) * sizeof(u64);
     p.part_bytes = (size_t)nq * p.S * k * sizeof(u64);
     return p;
@@ -399,16 +442,16 @@ size_t gemm_topk_workspace(const rag_index* h, long long nq, int k) {
     return p.cand_bytes + p.part_bytes;
 }
 
-template <int RT, int QT>
+template <int RT, int QT, int NW>
 static int launch_gemm(const GemmArgs& a, int grid, int device, hipStream_t s) {
     const size_t lds = (size_t)(2 * (RT + QT) * GK) * sizeof(float) + QT * 8 + 16;
     static bool attr_set[64] = {};          // per device: the attribute belongs to the device's code object
     if (!attr_set[device & 63]) {
-        RAG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_topk_kernel<RT, QT>),
+        RAG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_topk_kernel<RT, QT, NW>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[device & 63] = true;
     }
-    hipLaunchKernelGGL((gemm_topk_kernel<RT, QT>), dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((gemm_topk_kernel<RT, QT, NW>), dim3(grid), dim3(NW * 64), lds, s, a);
     RAG_HIP_CHECK(hipGetLastError());
     return RAG_OK;
 }
@@ -427,6 +470,7 @@ int gemm_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float
     a.nqb = p.nqb;
     a.nqb_pad = p.nqb_pad;
     a.S = p.S;
+    a.gq = p.gq;
     const int grid = p.nqb_pad * p.S;
     // workspace: [queries | candidate buffers | partial keys]
     const size_t qbytes = ((size_t)nq * h->ld * sizeof(float) + 255) & ~(size_t)255;
@@ -437,9 +481,10 @@ int gemm_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float
     a.part = reinterpret_cast<u64*>(static_cast<char*>(h->ws.ptr) + qbytes + p.cand_bytes);
     if (int rc = profile_begin(h, s)) return rc;
     int rc;
-    if (p.QT == 32) rc = launch_gemm<256, 32>(a, grid, h->device, s);
-    else if (p.QT == 64) rc = launch_gemm<128, 64>(a, grid, h->device, s);
-    else rc = launch_gemm<128, 128>(a, grid, h->device, s);
+    if (p.QT == 32) rc = launch_gemm<256, 32, 4>(a, grid, h->device, s);
+    else if (p.QT == 64) rc = launch_gemm<128, 64, 4>(a, grid, h->device, s);
+    else if (p.QT == 256) rc = launch_gemm<256, 256, 8>(a, grid, h->device, s);
+    else rc = launch_gemm<128, 128, 4>(a, grid, h->device, s);
     if (rc) return rc;
     if (int rc2 = profile_end(h, s)) return rc2;
     MergeArgs m = {};

@@ -28,7 +28,9 @@ def _check(D, I, X, Q, k, **kw):
     (3, 768, 20, 10), (50_000, 768, 2048, 10),
     # the narrow tile shapes (<= 32 and <= 64 queries per block, 256-row tiles)
     (40_000, 768, 9, 10), (40_000, 768, 32, 10), (40_001, 768, 33, 10), (25_000, 1024, 64, 64),
-    (300, 64, 12, 10), (1_000, 256, 48, 3), (255, 384, 31, 10), (257, 384, 50, 64)])
+    (300, 64, 12, 10), (1_000, 256, 48, 3), (255, 384, 31, 10), (257, 384, 50, 64),
+    # the 256 x 256 shape (8 waves) from 1024 queries
+    (20_000, 768, 1024, 10), (513, 1024, 1500, 64), (70_000, 384, 4096, 10)])
 def test_gemm_matches_oracle(n, d, nq, k):
     from rag_amd import DeviceIndex
     rng = np.random.default_rng(n * 7 + d + nq)
@@ -42,7 +44,7 @@ def test_gemm_matches_oracle(n, d, nq, k):
     idx.close()
 
 
-@pytest.mark.parametrize("nq", [20, 64, 130])
+@pytest.mark.parametrize("nq", [20, 64, 130, 1030])
 def test_gemm_adversarial_order_duplicates_and_mask(nq):
     """Rows sorted by increasing score for one query make every row a candidate
     (the buffers must compact, never overflow); duplicate rows tie exactly.
