@@ -177,21 +177,35 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(ScanArgs a) {
                 }
             }
         } else {
-            for (int c = 0; c < nch; ++c) {
-                const int col = c * LPR + l;
-                const bool in = col < d4;
-                f4 x[U];
+            // run-time chunk count: three chunks of every row of the tile per round, so that a
+            // wave keeps 3*U loads in flight as the compile-time paths do
+            constexpr int CG = 3;
+            for (int c0 = 0; c0 < nch; c0 += CG) {
+                f4 x[U][CG];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     long long r = row0 + u * RPS + sub;
                     r = r < r_end ? r : r_end - 1;
-                    x[u] = in ? load_row4<NT>(X4 + r * (long long)d4 + col) : f4_zero();
+                    const f4* xr = X4 + r * (long long)d4;
+#pragma unroll
+                    for (int g = 0; g < CG; ++g) {
+                        // always load (a clamped column of the same row) and select afterwards: a
+                        // load under a branch is waited for before the next one is issued
+                        const int col = (c0 + g) * LPR + l;
+                        const f4 v = load_row4<NT>(xr + (col < d4 ? col : d4 - 1));
+                        x[u][g] = (col < d4) ? v : f4_zero();
+                    }
                 }
 #pragma unroll
-                for (int qi = 0; qi < NQ; ++qi) {
-                    const f4 qv = in ? qlds[qi * d4 + col] : f4_zero();
+                for (int g = 0; g < CG; ++g) {
+                    const int col = (c0 + g) * LPR + l;
 #pragma unroll
-                    for (int u = 0; u < U; ++u) acc[u][qi] = dot4(x[u], qv, acc[u][qi]);
+                    for (int qi = 0; qi < NQ; ++qi) {
+                        const f4 qraw = qlds[qi * d4 + (col < d4 ? col : d4 - 1)];
+                        const f4 qv = (col < d4) ? qraw : f4_zero();
+#pragma unroll
+                        for (int u = 0; u < U; ++u) acc[u][qi] = dot4(x[u][g], qv, acc[u][qi]);
+                    }
                 }
             }
         }
@@ -504,6 +518,8 @@ static hipError_t launch_scan_nq(const ScanArgs& a, int blocks, size_t lds, hipS
     // compile-time chunk counts for the common embedding widths
     if (d4 == 192) return launch_scan_t<64, 3, 4, NQ, BIGK>(a, blocks, lds, s);          // d = 768
     if (d4 == 256) return launch_scan_t<64, 4, 2, NQ, BIGK>(a, blocks, lds, s);          // d = 1024
+    if (d4 == 384) return launch_scan_t<64, 6, 2, NQ, BIGK>(a, blocks, lds, s);          // d = 1536
+    if (d4 == 768) return launch_scan_t<64, 12, 1, NQ, BIGK>(a, blocks, lds, s);         // d = 3072
     if (d4 == 96) return launch_scan_t<32, 3, 4, NQ, BIGK>(a, blocks, lds, s);           // d = 384
     if (d4 == 128) return launch_scan_t<64, 2, 4, NQ, BIGK>(a, blocks, lds, s);          // d = 512
     if (d4 == 64) return launch_scan_t<64, 1, 4, NQ, BIGK>(a, blocks, lds, s);           // d = 256
@@ -517,7 +533,8 @@ static hipError_t launch_scan_nq(const ScanArgs& a, int blocks, size_t lds, hipS
 int scan_lists_per_block(int k) { return k > 64 ? 4 : 1; }
 
 int scan_rows_per_tile(int d4) {
-    if (d4 == 256) return 2;
+    if (d4 == 256 || d4 == 384) return 2;
+    if (d4 == 768) return 1;
     if (d4 == 96 || d4 == 32) return 8;
     if (d4 <= 16) return 16;
     if (d4 < 32) return 8;
@@ -535,7 +552,7 @@ hipError_t launch_flat_scan(ScanArgs a, int nq, int blocks, hipStream_t s) {
     const int lpr = scan_lanes_per_row(a.d4);
     a.nch = (a.d4 + lpr - 1) / lpr;
     // queries live in registers only for NQ == 1 with a compile-time chunk count
-    const bool q_in_regs = (nq == 1) && (a.d4 == 192 || a.d4 == 256 || a.d4 == 96 || a.d4 == 128 || a.d4 == 64 || a.d4 == 32 || a.d4 <= 16);
+    const bool q_in_regs = (nq == 1) && (a.d4 == 192 || a.d4 == 256 || a.d4 == 384 || a.d4 == 768 || a.d4 == 96 || a.d4 == 128 || a.d4 == 64 || a.d4 == 32 || a.d4 <= 16);
     size_t lds = q_in_regs ? 0 : (((size_t)nq * a.d4 * 16 + 15) & ~(size_t)15);
     if (!bigk) lds += (size_t)nq * 3 * 64 * sizeof(u64);          // lists of waves 1..3, merged by wave 0
     if (bigk) {

@@ -14,7 +14,7 @@
 //      256 x 256   4 x 2 (8 waves)          64 x 128, 2x4 MFMA  nq >= 1024
 //      128 x 128   2 x 2                    64 x 64, 2x2 MFMA   64 < nq < 1024
 //      128 x 64    2 x 2                    64 x 32, 2x1 MFMA   32 < nq <= 64
-//      256 x 32    4 x 1                    64 x 32, 2x1 MFMA   nq <= 32
+//      256 x 32    4 x 1                    64 x 32, 2x1 MFMA   5 <= nq <= 32
 // The narrow shapes spend no matrix-core time on padding queries: a batch of 32
 // costs about one HBM pass over the corpus instead of a 128-query tile's work.
 // Corpus rows sit on the MFMA's row index (registers), queries on its column
@@ -393,7 +393,7 @@ static int env_int_g(const char* name, int dflt) {
 }
 
 bool gemm_topk_supported(const rag_index* h, long long nq, int k) {
-    static const int min_nq = env_int_g("RAG_GEMM_MIN_NQ", 9);
+    static const int min_nq = env_int_g("RAG_GEMM_MIN_NQ", 5);
     return h->kind == RAG_KIND_FLAT && nq >= min_nq && k <= GEMM_MAX_K && (h->ld % GK) == 0 && h->n >= 1;
 }
 
