@@ -72,6 +72,13 @@ int rag_index_adopt_device(rag_index_t* h, int64_t n, float* x_dev);
 /* ids reported for rows without explicit ids start here (row shard of a
  * multi-GPU corpus: base = first global row of the shard) */
 int rag_index_set_id_base(rag_index_t* h, int64_t base);
+/* Optional acceleration of large batches (vector_db/search_optimizer.py:276-323 batch_search,
+ * from 1024 queries, dim % 64 == 0, FLAT): mode 1 keeps a bf16 copy of the rows, runs the
+ * contraction on bf16 matrix cores and keeps every row whose approximate score is within a
+ * proven error margin of the k-th best; those rows are re-scored in fp32 and the k best are
+ * returned, so ids and scores are those of the fp32 path.  Costs dim*2 bytes per row of device
+ * memory.  mode 0 (default) switches it off and frees the copy. */
+int rag_index_set_prefilter(rag_index_t* h, int mode);
 int64_t rag_index_ntotal(const rag_index_t* h);
 int rag_index_dim(const rag_index_t* h);
 /* vector_db/qdrant_client.py:826-883 soft delete (payload is_active) and

@@ -243,7 +243,7 @@ static int flat_scan_search(rag_index* h, long long nq, const float* qbuf, int k
         if (int rc = profile_begin(h, s)) return rc;
         RAG_HIP_CHECK(launch_flat_scan(a, g, blocks, s));
         if (int rc = profile_end(h, s)) return rc;
-        MergeArgs m;
+        MergeArgs m = {};
         m.keys = part;
         m.per_query = lists * k;
         m.k = k;
@@ -335,6 +335,8 @@ int rag_index_free(rag_index_t* h) {
     if (h->active) (void)hipFree(h->active);
     for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
     if (h->ws_event) (void)hipEventDestroy(h->ws_event);
+    if (h->Xb) (void)hipFree(h->Xb);
+    if (h->xb_maxnorm) (void)hipFree(h->xb_maxnorm);
     ivf_free(h);
     h->ws.release();
     h->ws2.release();
@@ -433,6 +435,22 @@ int rag_index_profile_read(rag_index_t* h, double* kernel_ms, int64_t* launches,
     *kernel_ms = total;
     *launches = (int64_t)(h->prof_used / 2);
     if (reset) h->prof_used = 0;
+    return RAG_OK;
+}
+
+int rag_index_set_prefilter(rag_index_t* h, int mode) {
+    if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
+    if (mode != 0 && mode != 1) return fail(RAG_ERR_INVALID, "prefilter mode must be 0 (off) or 1 (bf16 first pass)");
+    if (mode == 1 && h->kind != RAG_KIND_FLAT) return fail(RAG_ERR_UNSUPPORTED, "the bf16 first pass needs a FLAT index");
+    DeviceGuard g(h->device);
+    if (mode == 0 && h->Xb) {
+        if (int rc = ws_acquire(h, h->stream)) return rc;
+        RAG_HIP_CHECK(hipStreamSynchronize(h->stream));
+        RAG_HIP_CHECK(hipFree(h->Xb));
+        h->Xb = nullptr;
+        h->xb_rows = h->xb_cap = 0;
+    }
+    h->prefilter = mode;
     return RAG_OK;
 }
 
@@ -695,7 +713,7 @@ int rag_merge_topk_device(int nlists, int64_t nq, int k, const float* D_dev, int
     if (int rc = ws.ensure((size_t)nq * nlists * k * sizeof(u64))) return rc;
     u64* keys = static_cast<u64*>(ws.ptr);
     RAG_HIP_CHECK(launch_lists_to_keys(nlists, nq, k, D_dev, d_list_stride, reinterpret_cast<const long long*>(I_dev), i_list_stride, keys, s));
-    MergeArgs m;
+    MergeArgs m = {};
     m.keys = keys;
     m.per_query = (long long)nlists * k;
     m.k = k;

@@ -318,6 +318,7 @@ __global__ __launch_bounds__(1024) void merge_keys_kernel(MergeArgs a) {
     int* s_cnt = reinterpret_cast<int*>(buf + cap + 1);   // [cap+1] keys in buf
     u64* cand = buf + cap + 2;                            // [MERGE_FAST_CAP] fast path only
     const long long q = blockIdx.x;
+    if (a.run_if && *a.run_if == 0) return;
     const u64* in = a.keys + (size_t)q * a.per_query;
 
     // ---- fast path: the input is P descending runs of k keys.  The k-th largest run head is a
@@ -387,6 +388,7 @@ __global__ __launch_bounds__(1024) void merge_keys_kernel(MergeArgs a) {
 // bitonic step.  The waves' lists are then merged pairwise (tree over LDS).
 __global__ __launch_bounds__(1024) void merge_keys_small_kernel(MergeArgs a) {
     __shared__ u64 s_lists[16 * 64];
+    if (a.run_if && *a.run_if == 0) return;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nw = blockDim.x >> 6;

@@ -39,9 +39,19 @@
 // and tightens the threshold.  At the end every query's k best keys go to `part`,
 // and merge_keys_kernel merges the row-range partials.
 //
+// Optional bf16 first pass (B16 = true).  The same kernel runs on bf16 copies of the corpus
+// and the queries with v_mfma_f32_32x32x16_bf16 (one MFMA per 16-byte fragment instead of
+// four) and keeps, per query, every row whose approximate score lies within a margin of the
+// k-th best one.  margin = 2 * delta with delta >= |approximate - exact| for every row
+// (delta = c * max row norm * query norm), so the exact top-k is a subset of the kept rows;
+// rescore_select_kernel re-scores them in fp32 and selects.  A buffer that cannot hold the
+// kept rows (many near ties) raises a flag and the batch is answered by the fp32 kernel.
+//
 // Placement.  blockIdx -> (query block, row range) is chosen so that the
 // workgroups of one XCD (blockIdx % 8) share few query blocks: their query tiles
 // stay in that XCD's L2 while the corpus streams through.
+#include <algorithm>
+
 #include "index.h"
 #include "topk_keys.h"
 
@@ -64,9 +74,6 @@ __host__ __device__ constexpr int gemm_capq(int RT, int QT) { return gemm_trig(R
 
 // Timing-only ablations for diagnostic builds (outputs are wrong when non-zero):
 // bit 0 skip the tile epilogue, bit 1 load global tiles only once, bit 2 barrier only twice,
-// bit 3 walk the accumulators but push nothing, bit 4 stop after the epilogue's ballot,
-// bit 5 no sort inside a compaction, bit 6 no sort in the final pass, bit 7 pushes store nothing,
-// bit 8 pushes skip the LDS counter, bit 9 count and print events of two workgroups,
 // bit 10 every load re-reads the first K step of the first tile (load issue cost without memory latency).
 #ifndef RAG_GEMM_DIAG
 #define RAG_GEMM_DIAG 0
@@ -78,7 +85,11 @@ struct GemmArgs {
     const float* Q;
     const uint8_t* mask;
     u64* cand;       // [grid][QT][TRIG + RT]
-    u64* part;       // [nq][S][k]
+    u64* part;       // [nq][S][outc]
+    const float* margin;   // bf16 pass: per query, how far below the k-th approximate score a row is kept
+    int* overflow;         // bf16 pass: set when a buffer cannot hold the kept rows
+    const int* run_if;     // when not NULL the kernel runs only if *run_if != 0
+    int outc;              // keys per (query, row range) in part: k, or PREF_OUTC for the bf16 pass
     long long n;
     long long ntiles;
     int nq;
@@ -105,27 +116,55 @@ __device__ RAG_GEMM_PUSH_ATTR void push_candidate(const GemmArgs& a, u64* cand, 
                                                          long long row, float sc) {
     constexpr int CAPQ = gemm_capq(RT, QT);
     if (row < a.n && (!a.mask || a.mask[row])) {
-        if (DIAG & 512) atomicAdd(&s_flag[1], 1);
-        const int pos = (DIAG & 256) ? 0 : atomicAdd(&s_cnt[ql], 1);
-        if (!(DIAG & 128)) cand[(size_t)ql * CAPQ + pos] = make_key(sc, (uint32_t)row);
+        const int pos = atomicAdd(&s_cnt[ql], 1);
+        cand[(size_t)ql * CAPQ + pos] = make_key(sc, (uint32_t)row);
         if (pos + 1 > gemm_trig(RT, QT)) *s_flag = 1;       // compact before the next tile can overflow it
     }
 }
 
-// one wave per query: sort the candidate buffer of every query that could overflow on the next tile
-template <int RT, int QT, int NW>
-__device__ __forceinline__ void compact_queries(u64* scratch, u64* cand, int* s_cnt, float* s_thr, int k, int wave, int lane) {
+constexpr int PREF_OUTC = 128;   // bf16 pass: keys a (query, row range) may hand to the re-scoring step
+
+// number of leading keys of a descending list whose score is above `thr` (wave-wide, n <= 512)
+__device__ __forceinline__ int count_above(const u64* sorted, int n, float thr, int lane) {
+    int kept = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        const bool above = i < n && sorted[i] != KEY_EMPTY && key_score(sorted[i]) > thr;
+        kept += __popcll(__ballot(above));
+    }
+    return kept;
+}
+
+// one wave per query: sort the candidate buffer of every query that could overflow on the next
+// tile, keep the k best (fp32) or every key within the margin of the k-th best (bf16 pass),
+// tighten the threshold
+template <int RT, int QT, int NW, bool B16>
+__device__ __forceinline__ void compact_queries(u64* scratch, u64* cand, int* s_cnt, float* s_thr, const float* s_margin,
+                                                int* overflow, int k, int wave, int lane) {
     constexpr int CAPQ = gemm_capq(RT, QT);
+    constexpr int TRIG = gemm_trig(RT, QT);
     for (int ql = wave; ql < QT; ql += NW) {
         const int c = s_cnt[ql];
-        if (c <= gemm_trig(RT, QT)) continue;            // wave-uniform
+        if (c <= TRIG) continue;            // wave-uniform
         const int n2 = pow2_ceil(c > k ? c : k);
         for (int i = lane; i < n2; i += 64) scratch[i] = (i < c) ? cand[(size_t)ql * CAPQ + i] : KEY_EMPTY;
-        if (!(DIAG & 32)) bitonic_sort_desc_lds(scratch, n2, lane, 64, SyncWave());
-        for (int i = lane; i < k; i += 64) cand[(size_t)ql * CAPQ + i] = scratch[i];
+        bitonic_sort_desc_lds(scratch, n2, lane, 64, SyncWave());
+        int keep = c < k ? c : k;
+        float thr = c >= k ? key_score(scratch[k - 1]) : -INFINITY;
+        if constexpr (B16) {
+            if (c >= k) {
+                thr -= s_margin[ql];
+                keep = count_above(scratch, c, thr, lane);
+                if (keep > TRIG) {           // more near ties than the buffer can carry over
+                    if (lane == 0) *overflow = 1;
+                    keep = TRIG;
+                }
+            }
+        }
+        for (int i = lane; i < keep; i += 64) cand[(size_t)ql * CAPQ + i] = scratch[i];
         if (lane == 0) {
-            s_cnt[ql] = c < k ? c : k;
-            if (c >= k) s_thr[ql] = key_score(scratch[k - 1]);
+            s_cnt[ql] = keep;
+            if (c >= k) s_thr[ql] = thr;
         }
         SyncWave()();
     }
@@ -152,8 +191,6 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f16v (&acc)[2][
         hit |= m > thr[nj];
     }
     if (__ballot(hit) != 0ull) {
-        if ((DIAG & 512) && (threadIdx.x & 63) == 0) atomicAdd(&s_flag[3], 1);
-        if (DIAG & 16) { if (thr[0] == 123.456f) *s_flag = 1; return; }
 #pragma unroll
         for (int nj = 0; nj < NJ; ++nj) {
             const int ql = qbase + nj * 32 + l31;
@@ -162,7 +199,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f16v (&acc)[2][
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float sc = acc[mi][nj][r];
-                    if (sc > thr[nj] && (!(DIAG & 8) || sc == 123.456f))
+                    if (sc > thr[nj])
                         push_candidate<RT, QT>(a, cand, s_cnt, s_flag, ql, rbase + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, sc);
                 }
             }
@@ -170,7 +207,9 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f16v (&acc)[2][
     }
 }
 
-template <int RT, int QT, int NW>
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+
+template <int RT, int QT, int NW, bool B16>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(GemmArgs a) {
     constexpr int NT = NW * 64;              // threads
     constexpr int WM = RT / 64;              // waves along the corpus rows
@@ -193,6 +232,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
     float* s_thr = Bs + 2 * TILEB;                                     // [QT]
     int* s_cnt = reinterpret_cast<int*>(s_thr + QT);                   // [QT]
     int* s_flag = s_cnt + QT;                                          // [1] (+3 pad)
+    float* s_margin = reinterpret_cast<float*>(s_flag + 4);            // [QT], bf16 pass only
+
+    if (a.run_if && *a.run_if == 0) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -218,18 +260,23 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
     if (qb >= a.nqb) return;
     const int q0 = qb * QT;
     const int k = a.k;
-    const int KT = a.ld / GK;
+    // a K step is 128 bytes of every row: 32 floats, or 64 bf16
+    const int KT = B16 ? a.ld / (2 * GK) : a.ld / GK;
     const long long t_begin = a.ntiles * sp / a.S;
     const long long t_end = a.ntiles * (sp + 1) / a.S;
     u64* cand = a.cand + (size_t)b * QT * CAPQ;
 
-    for (int i = tid; i < QT; i += NT) { s_thr[i] = -INFINITY; s_cnt[i] = 0; }
-    if (tid == 0) { *s_flag = 0; if (DIAG & 512) { s_flag[1] = 0; s_flag[2] = 0; s_flag[3] = 0; } }
+    for (int i = tid; i < QT; i += NT) {
+        s_thr[i] = -INFINITY;
+        s_cnt[i] = 0;
+        if constexpr (B16) s_margin[i] = (q0 + i) < a.nq ? a.margin[q0 + i] : 0.f;
+    }
+    if (tid == 0) *s_flag = 0;
     __syncthreads();
 
     const f4* X4 = reinterpret_cast<const f4*>(a.X);
     const f4* Q4 = reinterpret_cast<const f4*>(a.Q);
-    const int ld4 = a.ld / 4;
+    const int ld4 = B16 ? a.ld / 8 : a.ld / 4;       // 16-byte chunks per row
 
     // ---- loader ------------------------------------------------------------------------
     // wave instruction i fills tile rows (APW*wave + i)*8 .. +7 (queries: BPW), lane -> (row = lane>>3,
@@ -295,10 +342,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
             // a candidate buffer filled up during the previous tile's epilogue: every wave has
             // passed the barrier above, so the flag is stable and stage buf^1 is idle
             if (kt == 0 && *s_flag != 0) {
-                compact_queries<RT, QT, NW>(reinterpret_cast<u64*>(As + (buf ^ 1) * TILEA) + wave * CAPQ2, cand, s_cnt, s_thr, k, wave, lane);
+                compact_queries<RT, QT, NW, B16>(reinterpret_cast<u64*>(As + (buf ^ 1) * TILEA) + wave * CAPQ2, cand, s_cnt, s_thr, s_margin,
+                                                 a.overflow, k, wave, lane);
                 __syncthreads();
                 if (tid == 0) *s_flag = 0;
-                if ((DIAG & 512) && tid == 0) s_flag[2] += 1;
             }
             if (!(DIAG & 2) || (t == t_begin && kt == 0)) {
                 if (DIAG & 1024) issue_load(0, buf ^ 1);       // same instructions, cache-resident source
@@ -317,7 +364,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
             for (int mi = 0; mi < 2; ++mi) fa[0][mi] = *reinterpret_cast<const f4*>(Ab + mi * 32 * GK + foff[0]);
 #pragma unroll
             for (int nj = 0; nj < NJ; ++nj) fb[0][nj] = *reinterpret_cast<const f4*>(Bb + nj * 32 * GK + foff[0]);
-            if (RAG_GEMM_SCHED == 1) __builtin_amdgcn_sched_group_barrier(0x100, READS, 0);
+            if (!B16 && RAG_GEMM_SCHED == 1) __builtin_amdgcn_sched_group_barrier(0x100, READS, 0);
 #pragma unroll
             for (int kb = 0; kb < GK / 8; ++kb) {
                 const int cur = kb & 1, nxt = cur ^ 1;
@@ -327,14 +374,26 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
 #pragma unroll
                     for (int nj = 0; nj < NJ; ++nj) fb[nxt][nj] = *reinterpret_cast<const f4*>(Bb + nj * 32 * GK + foff[kb + 1]);
                 }
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
+                if constexpr (B16) {
+                    // a 16-byte fragment is 8 bf16 = the whole K extent of one 32x32x16 MFMA
 #pragma unroll
                     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                         for (int nj = 0; nj < NJ; ++nj)
-                            acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][mi][s], fb[cur][nj][s], acc[mi][nj], 0, 0, 0);
-                if (RAG_GEMM_SCHED == 1) {
+                            acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, fa[cur][mi]),
+                                                                                  __builtin_bit_cast(bf8, fb[cur][nj]), acc[mi][nj], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                            for (int nj = 0; nj < NJ; ++nj)
+                                acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][mi][s], fb[cur][nj][s], acc[mi][nj], 0, 0, 0);
+                }
+                if (B16) {
+                    // the compiler's own order
+                } else if (RAG_GEMM_SCHED == 1) {
                     if (kb + 1 < GK / 8) {
 #pragma unroll
                         for (int j = 0; j < READS; ++j) {
@@ -370,8 +429,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
 
     // ---- final: every query's k best keys of this row range -> part ---------------------
     __syncthreads();
-    if ((DIAG & 512) && tid == 0 && (b == 0 || b == 300))
-        printf("wg %d tiles %lld lane-pushes %d compactions %d slow-path wave entries %d\n", b, (long long)(t_end - t_begin), s_flag[1], s_flag[2], s_flag[3]);
     {
         u64* scratch = reinterpret_cast<u64*>(As) + wave * CAPQ2;
         for (int ql = wave; ql < QT; ql += NW) {
@@ -379,12 +436,157 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
             const int c = s_cnt[ql];
             const int n2 = pow2_ceil(c > k ? c : k);
             for (int i = lane; i < n2; i += 64) scratch[i] = (i < c) ? cand[(size_t)ql * CAPQ + i] : KEY_EMPTY;
-            if (!(DIAG & 64)) bitonic_sort_desc_lds(scratch, n2, lane, 64, SyncWave());
-            u64* out = a.part + ((size_t)(q0 + ql) * a.S + sp) * k;
-            for (int i = lane; i < k; i += 64) out[i] = scratch[i];
+            bitonic_sort_desc_lds(scratch, n2, lane, 64, SyncWave());
+            u64* out = a.part + ((size_t)(q0 + ql) * a.S + sp) * a.outc;
+            if constexpr (B16) {
+                int keep = c;
+                if (c >= k) keep = count_above(scratch, c, key_score(scratch[k - 1]) - s_margin[ql], lane);
+                if (keep > PREF_OUTC) {
+                    if (lane == 0) *a.overflow = 1;
+                    keep = PREF_OUTC;
+                }
+                for (int i = lane; i < PREF_OUTC; i += 64) out[i] = i < keep ? scratch[i] : KEY_EMPTY;
+            } else {
+                for (int i = lane; i < k; i += 64) out[i] = scratch[i];
+            }
             SyncWave()();
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Second step of the bf16 pass, one workgroup per query: gather the keys the row ranges kept,
+// find the k-th best approximate score, re-score in fp32 every row within the margin of it,
+// select the k best exact scores.
+struct RescoreArgs {
+    const u64* part;        // [nq][S * PREF_OUTC]
+    int per_query;          // S * PREF_OUTC
+    const float* X;         // fp32 rows
+    const float* Q;         // fp32 padded queries
+    const float* margin;
+    int ld;
+    int* overflow;
+    MergeArgs fin;          // k, min_score, id mapping, D, I
+};
+constexpr int RESC_CAP = 4096;      // keys of one query that fit the selection buffer
+
+__device__ __forceinline__ void finalise_scored(const MergeArgs& a, long long q, int j, u64 key) {
+    float s = -3.402823466e+38f;
+    long long id = -1;
+    if (key != KEY_EMPTY) {
+        const float sc = key_score(key);
+        if (sc >= a.min_score) {
+            const uint32_t row = key_row(key);
+            s = sc;
+            id = a.row_ids ? a.row_ids[row] : a.id_base + (long long)row;
+        }
+    }
+    a.D[(size_t)q * a.k + j] = s;
+    a.I[(size_t)q * a.k + j] = id;
+}
+
+__global__ __launch_bounds__(256) void rescore_select_kernel(RescoreArgs r) {
+    __shared__ u64 buf[RESC_CAP];
+    __shared__ int s_n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long q = blockIdx.x;
+    const int k = r.fin.k;
+    const u64* in = r.part + (size_t)q * r.per_query;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    for (int i = tid; i < r.per_query; i += 256) {
+        const u64 key = in[i];
+        if (key != KEY_EMPTY) {
+            const int pos = atomicAdd(&s_n, 1);
+            if (pos < RESC_CAP) buf[pos] = key;
+        }
+    }
+    __syncthreads();
+    int n = s_n;
+    if (n > RESC_CAP) {
+        if (tid == 0) *r.overflow = 1;
+        n = RESC_CAP;
+    }
+    int n2 = pow2_ceil(n > 1 ? n : 1);
+    for (int i = n + tid; i < n2; i += 256) buf[i] = KEY_EMPTY;
+    bitonic_sort_desc_lds(buf, n2, tid, 256, SyncBlock());
+    // rows to re-score: everything above (k-th approximate score - margin); all of them when fewer than k
+    const float thr = n >= k ? key_score(buf[k - 1]) - r.margin[q] : -INFINITY;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256)
+        if (key_score(buf[i]) > thr) atomicAdd(&s_n, 1);        // a prefix of the sorted list
+    __syncthreads();
+    const int m = s_n;
+    // exact fp32 inner products, one wave per row
+    const f4* q4 = reinterpret_cast<const f4*>(r.Q + (size_t)q * r.ld);
+    const int ld4 = r.ld / 4;
+    for (int i = wave; i < m; i += 4) {
+        const uint32_t row = key_row(buf[i]);
+        const f4* x4 = reinterpret_cast<const f4*>(r.X + (size_t)row * r.ld);
+        float acc = 0.f;
+        for (int c = lane; c < ld4; c += 64) {
+            const f4 x = x4[c], y = q4[c];
+            acc = fmaf(x.x, y.x, acc);
+            acc = fmaf(x.y, y.y, acc);
+            acc = fmaf(x.z, y.z, acc);
+            acc = fmaf(x.w, y.w, acc);
+        }
+        acc = wave_sum_to_lane63(acc);
+        if (lane == 63) buf[i] = make_key(acc, row);
+    }
+    __syncthreads();
+    n2 = pow2_ceil(m > 1 ? m : 1);
+    for (int i = m + tid; i < n2; i += 256) buf[i] = KEY_EMPTY;
+    bitonic_sort_desc_lds(buf, n2, tid, 256, SyncBlock());
+    for (int j = tid; j < k; j += 256) finalise_scored(r.fin, q, j, j < m ? buf[j] : KEY_EMPTY);
+}
+
+// fp32 rows -> bf16 (round to nearest even); the largest row norm seen so far is kept as the
+// bit pattern of a non-negative float, which orders like an integer
+__global__ void rows_to_bf16_kernel(const float* X, long long r0, long long r1, int ld, __bf16* Xb, int* maxnorm_bits) {
+    typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63;
+    const long long wave = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
+    const long long nw = ((long long)gridDim.x * blockDim.x) >> 6;
+    const int ld4 = ld / 4;                       // rows are padded to a multiple of 4 floats
+    for (long long r = r0 + wave; r < r1; r += nw) {
+        const f4* src = reinterpret_cast<const f4*>(X + r * ld);
+        bf4* dst = reinterpret_cast<bf4*>(Xb + r * ld);
+        float ss = 0.f;
+        for (int i = lane; i < ld4; i += 64) {
+            const f4 v = src[i];
+            ss = fmaf(v.x, v.x, ss);
+            ss = fmaf(v.y, v.y, ss);
+            ss = fmaf(v.z, v.z, ss);
+            ss = fmaf(v.w, v.w, ss);
+            bf4 o;
+            o.x = (__bf16)v.x;
+            o.y = (__bf16)v.y;
+            o.z = (__bf16)v.z;
+            o.w = (__bf16)v.w;
+            dst[i] = o;
+        }
+        ss = wave_sum_to_lane63(ss);
+        if (lane == 63) atomicMax(maxnorm_bits, __float_as_int(sqrtf(ss)));
+    }
+}
+
+// padded fp32 queries -> bf16 copies and the per-query margin 2 * delta,
+// delta = PREF_ERR * (largest row norm) * (query norm)
+constexpr float PREF_ERR = 0.0042f;      // 2 * 2^-9 (both operands rounded) + 2^-18 + accumulation slack
+__global__ void queries_to_bf16_kernel(const float* Q, int ld, const int* maxnorm_bits, __bf16* Qb, float* margin) {
+    const long long q = blockIdx.x;
+    const int lane = threadIdx.x;            // one wave per query
+    const float* src = Q + q * ld;
+    float ss = 0.f;
+    for (int i = lane; i < ld; i += 64) {
+        const float v = src[i];
+        ss = fmaf(v, v, ss);
+        Qb[q * ld + i] = (__bf16)v;
+    }
+    ss = wave_sum_to_lane63(ss);
+    if (lane == 63) margin[q] = 2.f * PREF_ERR * __int_as_float(*maxnorm_bits) * sqrtf(ss) * 1.0001f + 1e-30f;
 }
 
 static int env_int_g(const char* name, int dflt) {
@@ -402,6 +604,8 @@ struct GemmPlan {
     int nqb, nqb_pad, S, gq;
     long long ntiles;
     size_t cand_bytes, part_bytes;
+    bool pref;                                   // bf16 first pass + fp32 re-scoring
+    size_t qb_bytes, margin_bytes, part16_bytes; // its extra workspace (then 256 bytes for the flag)
 };
 
 // tile shape, (query blocks, padded query blocks, row ranges) and workspace for a batch of nq queries
@@ -432,34 +636,63 @@ static GemmPlan gemm_plan(const rag_index* h, long long nq, int k) {
     }
     if (gq_env == 0) p.gq = 0;
     p.cand_bytes = (size_t)p.nqb_pad * p.S * p.QT * gemm_capq(p.RT, p.QT) * sizeof(u64);
-    p.part_bytes = (size_t)nq * p.S * k * sizeof(u64);
+    p.part_bytes = ((size_t)nq * p.S * k * sizeof(u64) + 255) & ~(size_t)255;
+    // the bf16 first pass pays off where the batch is MFMA-bound: the 256 x 256 shape
+    p.pref = h->prefilter && p.QT == 256 && (h->ld % (2 * GK)) == 0 && (long long)p.S * PREF_OUTC <= 16384;
+    p.qb_bytes = p.pref ? (((size_t)nq * h->ld * 2 + 255) & ~(size_t)255) : 0;
+    p.margin_bytes = p.pref ? (((size_t)nq * sizeof(float) + 255) & ~(size_t)255) : 0;
+    p.part16_bytes = p.pref ? (size_t)nq * p.S * PREF_OUTC * sizeof(u64) : 0;
     return p;
 }
 
 // bytes of workspace the gemm path needs after the padded queries
 size_t gemm_topk_workspace(const rag_index* h, long long nq, int k) {
     const GemmPlan p = gemm_plan(h, nq, k);
-    return p.cand_bytes + p.part_bytes;
+    return p.cand_bytes + p.part_bytes + p.qb_bytes + p.margin_bytes + p.part16_bytes + (p.pref ? 256 : 0);
 }
 
-template <int RT, int QT, int NW>
+template <int RT, int QT, int NW, bool B16 = false>
 static int launch_gemm(const GemmArgs& a, int grid, int device, hipStream_t s) {
-    const size_t lds = (size_t)(2 * (RT + QT) * GK) * sizeof(float) + QT * 8 + 16;
+    const size_t lds = (size_t)(2 * (RT + QT) * GK) * sizeof(float) + QT * 8 + 16 + (B16 ? QT * 4 : 0);
     static bool attr_set[64] = {};          // per device: the attribute belongs to the device's code object
     if (!attr_set[device & 63]) {
-        RAG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_topk_kernel<RT, QT, NW>),
+        RAG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_topk_kernel<RT, QT, NW, B16>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[device & 63] = true;
     }
-    hipLaunchKernelGGL((gemm_topk_kernel<RT, QT, NW>), dim3(grid), dim3(NW * 64), lds, s, a);
+    hipLaunchKernelGGL((gemm_topk_kernel<RT, QT, NW, B16>), dim3(grid), dim3(NW * 64), lds, s, a);
     RAG_HIP_CHECK(hipGetLastError());
+    return RAG_OK;
+}
+
+// bring the bf16 copy of the rows up to date (rows are only ever appended)
+static int prefilter_sync_rows(rag_index* h, hipStream_t s) {
+    if (h->xb_cap < h->n || !h->Xb) {
+        if (h->Xb) RAG_HIP_CHECK(hipFree(h->Xb));
+        h->Xb = nullptr;
+        h->xb_rows = 0;
+        h->xb_cap = std::max(h->cap, h->n);
+        RAG_HIP_CHECK(hipMalloc((void**)&h->Xb, (size_t)h->xb_cap * h->ld * sizeof(uint16_t)));
+    }
+    if (!h->xb_maxnorm) {
+        RAG_HIP_CHECK(hipMalloc((void**)&h->xb_maxnorm, 256));
+        RAG_HIP_CHECK(hipMemsetAsync(h->xb_maxnorm, 0, 256, s));
+    }
+    if (h->xb_rows < h->n) {
+        long long blocks = (h->n - h->xb_rows + 3) / 4;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(rows_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, h->X, h->xb_rows, h->n, h->ld,
+                           reinterpret_cast<__bf16*>(h->Xb), h->xb_maxnorm);
+        RAG_HIP_CHECK(hipGetLastError());
+        h->xb_rows = h->n;
+    }
     return RAG_OK;
 }
 
 int gemm_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask,
                      float* D, long long* I, hipStream_t s) {
     const GemmPlan p = gemm_plan(h, nq, k);
-    GemmArgs a;
+    GemmArgs a = {};
     a.X = h->X;
     a.mask = mask;
     a.n = h->n;
@@ -471,22 +704,16 @@ int gemm_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float
     a.nqb_pad = p.nqb_pad;
     a.S = p.S;
     a.gq = p.gq;
+    a.outc = k;
     const int grid = p.nqb_pad * p.S;
-    // workspace: [queries | candidate buffers | partial keys]
+    // workspace: [queries | candidate buffers | partial keys | bf16 queries | margins | kept keys | flag]
     const size_t qbytes = ((size_t)nq * h->ld * sizeof(float) + 255) & ~(size_t)255;
-    if (h->ws.bytes < qbytes + p.cand_bytes + p.part_bytes)
+    if (h->ws.bytes < qbytes + gemm_topk_workspace(h, nq, k))
         return fail(RAG_ERR_INVALID, "internal: workspace not sized for the gemm path");
+    char* w = static_cast<char*>(h->ws.ptr) + qbytes;
     a.Q = qbuf;
-    a.cand = reinterpret_cast<u64*>(static_cast<char*>(h->ws.ptr) + qbytes);
-    a.part = reinterpret_cast<u64*>(static_cast<char*>(h->ws.ptr) + qbytes + p.cand_bytes);
-    if (int rc = profile_begin(h, s)) return rc;
-    int rc;
-    if (p.QT == 32) rc = launch_gemm<256, 32, 4>(a, grid, h->device, s);
-    else if (p.QT == 64) rc = launch_gemm<128, 64, 4>(a, grid, h->device, s);
-    else if (p.QT == 256) rc = launch_gemm<256, 256, 8>(a, grid, h->device, s);
-    else rc = launch_gemm<128, 128, 4>(a, grid, h->device, s);
-    if (rc) return rc;
-    if (int rc2 = profile_end(h, s)) return rc2;
+    a.cand = reinterpret_cast<u64*>(w);
+    a.part = reinterpret_cast<u64*>(w + p.cand_bytes);
     MergeArgs m = {};
     m.keys = a.part;
     m.per_query = (long long)a.S * k;
@@ -497,6 +724,55 @@ int gemm_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float
     m.id_base = h->id_base;
     m.D = D;
     m.I = I;
+
+    if (p.pref) {
+        // bf16 pass over bf16 copies, fp32 re-scoring of the kept rows, and -- only if a buffer
+        // overflowed -- the fp32 kernel below, which then redoes the whole batch
+        if (int rc = prefilter_sync_rows(h, s)) return rc;
+        __bf16* qb = reinterpret_cast<__bf16*>(w + p.cand_bytes + p.part_bytes);
+        float* margin = reinterpret_cast<float*>(w + p.cand_bytes + p.part_bytes + p.qb_bytes);
+        u64* part16 = reinterpret_cast<u64*>(w + p.cand_bytes + p.part_bytes + p.qb_bytes + p.margin_bytes);
+        int* flag = reinterpret_cast<int*>(w + p.cand_bytes + p.part_bytes + p.qb_bytes + p.margin_bytes + p.part16_bytes);
+        RAG_HIP_CHECK(hipMemsetAsync(flag, 0, 256, s));
+        hipLaunchKernelGGL(queries_to_bf16_kernel, dim3((unsigned)nq), dim3(64), 0, s, qbuf, h->ld, h->xb_maxnorm, qb, margin);
+        RAG_HIP_CHECK(hipGetLastError());
+        GemmArgs b = a;
+        b.X = reinterpret_cast<const float*>(h->Xb);
+        b.Q = reinterpret_cast<const float*>(qb);
+        b.part = part16;
+        b.margin = margin;
+        b.overflow = flag;
+        b.outc = PREF_OUTC;
+        if (int rc = profile_begin(h, s)) return rc;
+        if (int rc = launch_gemm<256, 256, 8, true>(b, grid, h->device, s)) return rc;
+        if (int rc = profile_end(h, s)) return rc;
+        RescoreArgs r = {};
+        r.part = part16;
+        r.per_query = p.S * PREF_OUTC;
+        r.X = h->X;
+        r.Q = qbuf;
+        r.margin = margin;
+        r.ld = h->ld;
+        r.overflow = flag;
+        r.fin = m;
+        hipLaunchKernelGGL(rescore_select_kernel, dim3((unsigned)nq), dim3(256), 0, s, r);
+        RAG_HIP_CHECK(hipGetLastError());
+        a.run_if = flag;
+        m.run_if = flag;
+        if (int rc = launch_gemm<256, 256, 8>(a, grid, h->device, s)) return rc;
+        RAG_HIP_CHECK(launch_merge_keys(m, nq, s));
+        h->last_path = "gemm-bf16";
+        return RAG_OK;
+    }
+
+    if (int rc = profile_begin(h, s)) return rc;
+    int rc;
+    if (p.QT == 32) rc = launch_gemm<256, 32, 4>(a, grid, h->device, s);
+    else if (p.QT == 64) rc = launch_gemm<128, 64, 4>(a, grid, h->device, s);
+    else if (p.QT == 256) rc = launch_gemm<256, 256, 8>(a, grid, h->device, s);
+    else rc = launch_gemm<128, 128, 4>(a, grid, h->device, s);
+    if (rc) return rc;
+    if (int rc2 = profile_end(h, s)) return rc2;
     RAG_HIP_CHECK(launch_merge_keys(m, nq, s));
     h->last_path = "gemm";
     return RAG_OK;

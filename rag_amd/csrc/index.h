@@ -75,6 +75,12 @@ struct rag_index {
     uint8_t* active = nullptr;      // nullptr = every row active
     long long n_inactive = 0;
     long long reserve_hint = 0;
+    // optional bf16 first pass of large batches: a bf16 copy of the rows and the largest row norm
+    int prefilter = 0;
+    uint16_t* Xb = nullptr;         // [xb_cap][ld] bf16
+    long long xb_rows = 0;          // rows [0, xb_rows) of Xb are current
+    long long xb_cap = 0;
+    int* xb_maxnorm = nullptr;      // device: bit pattern of the largest row norm converted so far
     rag::Workspace ws;              // queries, partial keys, staging
     rag::Workspace ws2;             // combined masks, host-API result staging
     hipStream_t stream = nullptr;   // used by the host-pointer entry points

@@ -216,7 +216,7 @@ int ivf_search_device(rag_index* h, long long nq, const float* qbuf, int k, floa
         if (int rc = profile_begin(h, s)) return rc;
         RAG_HIP_CHECK(launch_flat_scan(a, 1, gx, s));
         if (int rc = profile_end(h, s)) return rc;
-        MergeArgs m;
+        MergeArgs m = {};
         m.keys = part;
         m.per_query = (long long)gx * scan_lists_per_block(k) * k;
         m.k = k;

@@ -44,6 +44,7 @@ struct MergeArgs {
     long long id_base;
     const long long* slot_ids;   // merge of finished lists: slot = list*k + rank lives at
     long long slot_stride;       //   slot_ids[list*slot_stride + q*k + rank]
+    const int* run_if;           // when not NULL the merge runs only if *run_if != 0
     float* D;                    // [nq][k]
     long long* I;                // [nq][k]
 };

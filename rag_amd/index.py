@@ -105,6 +105,11 @@ class DeviceIndex:
     def set_id_base(self, base: int) -> None:
         check(lib.rag_index_set_id_base(self._h, int(base)))
 
+    def set_prefilter(self, enabled: bool) -> None:
+        """bf16 first pass for batches of 1024+ queries (results are re-scored in fp32 and equal
+        those of the fp32 path); keeps a bf16 copy of the rows on the device."""
+        check(lib.rag_index_set_prefilter(self._h, 1 if enabled else 0))
+
     def add(self, x, ids=None) -> None:
         ids_np = None if ids is None else np.ascontiguousarray(ids, dtype=np.int64)
         if _is_torch_cuda(x):

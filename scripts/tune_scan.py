@@ -21,6 +21,8 @@ X = make_corpus(torch, 0, rows, dim, dev)
 Q = make_queries(torch, max(nq, 64), dim, dev)
 idx = DeviceIndex(dim, metric="ip")
 idx.adopt(X)
+if os.environ.get("PREFILTER", "0") == "1":
+    idx.set_prefilter(True)
 idx.profile(True)
 for i in range(int(os.environ.get("WARMUP", 5))):
     idx.search(Q[:nq], k)

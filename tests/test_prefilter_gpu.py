@@ -1,0 +1,71 @@
+"""The optional bf16 first pass of large batches (rag_index_set_prefilter): the
+kept rows are re-scored in fp32, so the answers must meet the same bar as the
+fp32 path -- ids equal to the oracle's except score ties within 1e-5 relative
+(+1e-6 absolute), scores within that tolerance."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-5, 1e-6
+
+
+def _unit(rng, n, d):
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return x
+
+
+def _check(D, I, X, Q, k, **kw):
+    from oracle import flat
+    Dr, Ir = flat.flat_ip_search(X, Q, k, **kw)
+    bad = flat.compare_topk(D, I, Dr, Ir, rtol=RTOL, atol=ATOL)
+    assert bad == [], bad[:5]
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(60_000, 768, 1024, 10), (30_000, 384, 1500, 64), (20_000, 1024, 2048, 1),
+                                      (700, 128, 1100, 10)])
+def test_prefilter_matches_oracle(n, d, nq, k):
+    from rag_amd import DeviceIndex
+    rng = np.random.default_rng(n + d + nq)
+    X = _unit(rng, n, d) * rng.uniform(0.5, 2.0, (n, 1)).astype(np.float32)      # row norms vary: the margin uses the largest
+    Q = _unit(rng, nq, d)
+    idx = DeviceIndex(d, metric="ip")
+    idx.add(X[: n // 2])
+    idx.set_prefilter(True)
+    D, I = idx.search(Q, k)
+    assert idx.last_path == "gemm-bf16"
+    _check(D, I, X[: n // 2], Q, k)
+    idx.add(X[n // 2:])                          # rows appended after the bf16 copy was made
+    D, I = idx.search(Q, k)
+    assert idx.last_path == "gemm-bf16"
+    _check(D, I, X, Q, k)
+    mask = (rng.uniform(size=n) < 0.3).astype(np.uint8)
+    D, I = idx.search(Q, k, row_mask=mask, min_score=0.02)
+    _check(D, I, X, Q, k, row_mask=mask, min_score=0.02)
+    idx.set_prefilter(False)
+    D2, I2 = idx.search(Q, k, row_mask=mask, min_score=0.02)
+    assert idx.last_path == "gemm"
+    _check(D2, I2, X, Q, k, row_mask=mask, min_score=0.02)
+    idx.close()
+
+
+def test_prefilter_falls_back_when_near_ties_overflow():
+    """Thousands of copies of one row tie exactly: every copy is within the margin of the k-th
+    best, the kept-row buffers overflow, and the batch is answered by the fp32 kernel -- the
+    result is still the exact one (lowest ids of the tied rows first)."""
+    from rag_amd import DeviceIndex
+    rng = np.random.default_rng(7)
+    n, d, nq, k = 40_000, 256, 1024, 10
+    X = _unit(rng, n, d)
+    X[5_000:25_000] = X[123]
+    Q = _unit(rng, nq, d)
+    Q[0] = X[123]
+    idx = DeviceIndex(d, metric="ip")
+    idx.add(X)
+    idx.set_prefilter(True)
+    D, I = idx.search(Q, k)
+    assert idx.last_path == "gemm-bf16"
+    _check(D, I, X, Q, k)
+    assert I[0].tolist() == [123] + list(range(5_000, 5_009))
+    idx.close()
