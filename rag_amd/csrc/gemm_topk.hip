@@ -614,7 +614,9 @@ static GemmPlan gemm_plan(const rag_index* h, long long nq, int k) {
     static const int force_qt = env_int_g("RAG_GEMM_QT", 0);
     static const int big_min_nq = env_int_g("RAG_GEMM_BIG_MIN_NQ", 1024);
     GemmPlan p;
-    p.QT = force_qt ? force_qt : (nq <= 32 ? 32 : nq <= 64 ? 64 : nq < big_min_nq ? 128 : 256);
+    // with the bf16 first pass on, the 256 x 256 shape (the one it runs in) already pays from 512 queries
+    const int big_from = h->prefilter ? std::min(big_min_nq, 512) : big_min_nq;
+    p.QT = force_qt ? force_qt : (nq <= 32 ? 32 : nq <= 64 ? 64 : nq < big_from ? 128 : 256);
     p.RT = (p.QT == 32 || p.QT == 256) ? 256 : 128;
     p.NW = p.QT == 256 ? 8 : 4;
     const int target_wgs = target_wgs_env > 0 ? target_wgs_env : (p.NW == 8 ? 256 : 512);
