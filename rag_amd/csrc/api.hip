@@ -167,6 +167,10 @@ size_t ivf_search_workspace(const rag_index* h, long long nq, int k, int nprobe)
 int gemm_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask,
                      float* D, long long* I, hipStream_t s);                 // gemm_topk.hip
 bool gemm_topk_supported(const rag_index* h, long long nq, int k);
+bool prefilter_scan_supported(const rag_index* h, long long nq, int k);       // gemm_topk.hip
+size_t prefilter_scan_workspace(const rag_index* h, int k);
+int prefilter_scan_search(rag_index* h, const float* qbuf, int k, float min_score, const uint8_t* mask,
+                          float* D, long long* I, hipStream_t s);
 size_t gemm_topk_workspace(const rag_index* h, long long nq, int k);
 int ivf_reconstruct_rows(rag_index* h, long long n, const int64_t* rows, std::vector<long long>& storage_rows);
 
@@ -182,7 +186,7 @@ int merge_cap(long long per_query, int k) {
 }
 
 // blocks for the scan: enough waves to fill the chip, not more lists than rows justify
-static int scan_blocks(const rag_index* h) {
+int scan_blocks(const rag_index* h) {
     static const int max_blocks = env_int("RAG_SCAN_BLOCKS", 512);
     const int tile = scan_rows_per_tile(h->ld / 4);
     const long long ntiles = (h->n + tile - 1) / tile;
@@ -265,6 +269,7 @@ static int flat_scan_search(rag_index* h, long long nq, const float* qbuf, int k
 // bytes the exhaustive search needs in h->ws after the padded queries
 size_t flat_search_workspace(const rag_index* h, long long nq, int k) {
     if (gemm_topk_supported(h, nq, k)) return gemm_topk_workspace(h, nq, k);
+    if (prefilter_scan_supported(h, nq, k)) return prefilter_scan_workspace(h, k);
     return (size_t)((k > 64) ? 1 : 8) * scan_blocks(h) * 4 * k * sizeof(u64);
 }
 
@@ -276,6 +281,7 @@ int flat_search_prepared(rag_index* h, long long nq, const float* qbuf, int k, f
     const size_t qbytes = ((size_t)nq * h->ld * sizeof(float) + 255) & ~(size_t)255;
     if (int rc = h->ws.ensure(qbytes + flat_search_workspace(h, nq, k))) return rc;
     if (gemm_topk_supported(h, nq, k)) return gemm_topk_search(h, nq, qbuf, k, min_score, mask, D, I, s);
+    if (prefilter_scan_supported(h, nq, k)) return prefilter_scan_search(h, qbuf, k, min_score, mask, D, I, s);
     return flat_scan_search(h, nq, qbuf, k, min_score, mask, D, I, s);
 }
 

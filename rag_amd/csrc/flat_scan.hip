@@ -37,6 +37,20 @@ __device__ __forceinline__ float dot4(const f4& a, const f4& b, float acc) {
     return acc;
 }
 __device__ __forceinline__ f4 f4_zero() { return (f4){0.f, 0.f, 0.f, 0.f}; }
+// a 16-byte chunk of a bf16 row holds elements e0..e7, two per dword (even in the low half):
+// bf16 -> fp32 is a shift, so the chunk unpacks into (e0,e2,e4,e6) and (e1,e3,e5,e7)
+__device__ __forceinline__ f4 bf16_even(const f4& raw) {
+    f4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = __uint_as_float(__float_as_uint(raw[j]) << 16);
+    return o;
+}
+__device__ __forceinline__ f4 bf16_odd(const f4& raw) {
+    f4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = __uint_as_float(__float_as_uint(raw[j]) & 0xFFFF0000u);
+    return o;
+}
 
 // LPR  lanes that share one row (64 / 32 / 16); RPS = 64/LPR rows per wave step
 // CH   float4 chunks per lane per row, compile time (0: run-time count a.nch)
@@ -51,11 +65,15 @@ __device__ __forceinline__ f4 load_row4(const f4* p) {
     else return *p;
 }
 
-template <int LPR, int CH, int U, int NQ, bool BIGK, bool NT>
+// B16  rows are bf16 (d4 counts their 16-byte chunks, 8 elements each), the query stays fp32;
+//      one query, register list, compile-time chunk count only
+template <int LPR, int CH, int U, int NQ, bool BIGK, bool NT, bool B16 = false>
 __global__ __launch_bounds__(256) void flat_scan_kernel(ScanArgs a) {
     constexpr int RPS = 64 / LPR;
     constexpr int TILE = RPS * U;
     static_assert(!BIGK || NQ == 1, "LDS-buffer selection handles one query per launch");
+    static_assert(!B16 || (NQ == 1 && !BIGK && CH > 0), "bf16 rows: one query, k <= 64, compile-time width");
+    if (a.run_if && *a.run_if == 0) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int lane = threadIdx.x & 63;
@@ -94,7 +112,7 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(ScanArgs a) {
     }
 
     // ---- query fragments --------------------------------------------------
-    constexpr int QREG = (NQ == 1 && CH > 0) ? CH : 1;
+    constexpr int QREG = (NQ == 1 && CH > 0) ? (B16 ? 2 * CH : CH) : 1;
     f4 qf[QREG];
     f4* qlds = reinterpret_cast<f4*>(smem);          // [NQ][d4] when not in registers
     constexpr bool Q_IN_REGS = (NQ == 1 && CH > 0);
@@ -102,7 +120,15 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(ScanArgs a) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const int col = c * LPR + l;
-            qf[c] = (col < d4) ? Q4[col] : f4_zero();
+            if constexpr (B16) {
+                // the fp32 query elements that face the even / odd elements of row chunk `col`
+                const f4 lo = (col < d4) ? Q4[2 * col] : f4_zero();
+                const f4 hi = (col < d4) ? Q4[2 * col + 1] : f4_zero();
+                qf[2 * c] = (f4){lo[0], lo[2], hi[0], hi[2]};
+                qf[2 * c + 1] = (f4){lo[1], lo[3], hi[1], hi[3]};
+            } else {
+                qf[c] = (col < d4) ? Q4[col] : f4_zero();
+            }
         }
     } else {
         const int valid = (a.nq_valid > 0 && a.nq_valid < NQ) ? a.nq_valid : NQ;
@@ -163,7 +189,13 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(ScanArgs a) {
             }
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
-                if constexpr (Q_IN_REGS) {
+                if constexpr (B16) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        acc[u][0] = dot4(bf16_even(x[u][c]), qf[2 * c], acc[u][0]);
+                        acc[u][0] = dot4(bf16_odd(x[u][c]), qf[2 * c + 1], acc[u][0]);
+                    }
+                } else if constexpr (Q_IN_REGS) {
 #pragma unroll
                     for (int u = 0; u < U; ++u) acc[u][0] = dot4(x[u][c], qf[c], acc[u][0]);
                 } else {
@@ -497,9 +529,9 @@ __global__ void gather_rows_kernel(const float* X, int d, int ld, long long n, c
 
 // ---------------------------------------------------------------------------
 // host-side launchers
-template <int LPR, int CH, int U, int NQ, bool BIGK, bool NT>
+template <int LPR, int CH, int U, int NQ, bool BIGK, bool NT, bool B16 = false>
 static hipError_t launch_scan_t2(const ScanArgs& a, int blocks, size_t lds, hipStream_t s) {
-    auto kern = flat_scan_kernel<LPR, CH, U, NQ, BIGK, NT>;
+    auto kern = flat_scan_kernel<LPR, CH, U, NQ, BIGK, NT, B16>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -510,6 +542,11 @@ static hipError_t launch_scan_t2(const ScanArgs& a, int blocks, size_t lds, hipS
 
 template <int LPR, int CH, int U, int NQ, bool BIGK>
 static hipError_t launch_scan_t(const ScanArgs& a, int blocks, size_t lds, hipStream_t s) {
+    if constexpr (NQ == 1 && !BIGK && CH > 0) {
+        if (a.b16) return a.nt ? launch_scan_t2<LPR, CH, U, 1, false, true, true>(a, blocks, lds, s)
+                               : launch_scan_t2<LPR, CH, U, 1, false, false, true>(a, blocks, lds, s);
+    }
+    if (a.b16) return hipErrorInvalidValue;
     return a.nt ? launch_scan_t2<LPR, CH, U, NQ, BIGK, true>(a, blocks, lds, s)
                 : launch_scan_t2<LPR, CH, U, NQ, BIGK, false>(a, blocks, lds, s);
 }

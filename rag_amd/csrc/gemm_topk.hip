@@ -50,6 +50,8 @@
 // Placement.  blockIdx -> (query block, row range) is chosen so that the
 // workgroups of one XCD (blockIdx % 8) share few query blocks: their query tiles
 // stay in that XCD's L2 while the corpus streams through.
+#include <float.h>
+
 #include <algorithm>
 
 #include "index.h"
@@ -777,6 +779,180 @@ int gemm_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float
     if (int rc2 = profile_end(h, s)) return rc2;
     RAG_HIP_CHECK(launch_merge_keys(m, nq, s));
     h->last_path = "gemm";
+    return RAG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// bf16 first pass for ONE query: the scan kernel over the bf16 copy of the rows (half the HBM
+// bytes) collects the PRE1 best approximate scores; verify_rescore_kernel re-scores those rows in
+// fp32 and accepts the k best exact ones only if the k-th of them beats (worst kept approximate
+// score + delta), delta >= |approximate - exact| for every row: then no row outside the kept set
+// can reach the top k.  Otherwise it raises the flag and the fp32 scan enqueued behind it
+// (run_if = flag) answers.  The query stays fp32, so delta = PREF_ERR1 * max row norm * |q|.
+constexpr int PRE1 = 64;
+constexpr float PREF_ERR1 = 0.0021f;     // 2^-9 (rows rounded to bf16) + accumulation slack
+
+int scan_blocks(const rag_index* h);     // api.hip
+
+struct VerifyArgs {
+    const float* Dk;        // [PRE1] approximate scores, descending, -FLT_MAX padded
+    const long long* Ik;    // [PRE1] row positions, -1 padded
+    const float* X;
+    const float* q;         // fp32 padded query
+    const int* maxnorm_bits;
+    int ld;
+    int* flag;
+    MergeArgs fin;
+};
+
+__global__ __launch_bounds__(256) void verify_rescore_kernel(VerifyArgs v) {
+    __shared__ u64 keys[PRE1];
+    __shared__ float s_qn;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = v.fin.k;
+    const f4* q4 = reinterpret_cast<const f4*>(v.q);
+    const int ld4 = v.ld / 4;
+    if (wave == 0) {
+        float ss = 0.f;
+        for (int c = lane; c < ld4; c += 64) {
+            const f4 y = q4[c];
+            ss = fmaf(y.x, y.x, ss);
+            ss = fmaf(y.y, y.y, ss);
+            ss = fmaf(y.z, y.z, ss);
+            ss = fmaf(y.w, y.w, ss);
+        }
+        ss = wave_sum_to_lane63(ss);
+        if (lane == 63) s_qn = sqrtf(ss);
+    }
+    for (int i = wave; i < PRE1; i += 4) {
+        const long long row = v.Ik[i];
+        u64 key = KEY_EMPTY;
+        if (row >= 0) {
+            const f4* x4 = reinterpret_cast<const f4*>(v.X + (size_t)row * v.ld);
+            float acc = 0.f;
+            for (int c = lane; c < ld4; c += 64) {
+                const f4 x = x4[c], y = q4[c];
+                acc = fmaf(x.x, y.x, acc);
+                acc = fmaf(x.y, y.y, acc);
+                acc = fmaf(x.z, y.z, acc);
+                acc = fmaf(x.w, y.w, acc);
+            }
+            acc = wave_sum_to_lane63(acc);
+            key = make_key(__shfl(acc, 63, 64), (uint32_t)row);
+        }
+        if (lane == 0) keys[i] = key;
+    }
+    __syncthreads();
+    bitonic_sort_desc_lds(keys, PRE1, tid, 256, SyncBlock());
+    // the kept set is everything when the list is not full; else rows outside score at most Dk[PRE1-1] + delta
+    const bool full = v.Ik[PRE1 - 1] >= 0;
+    const float delta = PREF_ERR1 * __int_as_float(*v.maxnorm_bits) * s_qn * 1.0001f + 1e-30f;
+    const bool enough = keys[k - 1] != KEY_EMPTY;
+    const bool ok = !full || (enough && key_score(keys[k - 1]) > v.Dk[PRE1 - 1] + delta);
+    if (tid == 0) *v.flag = ok ? 0 : 1;
+    if (ok)
+        for (int j = tid; j < k; j += 256) finalise_scored(v.fin, 0, j, keys[j]);
+}
+
+static bool b16_scan_width(int ld) {
+    if (ld % 8) return false;
+    const int c = ld / 8;       // 16-byte chunks per bf16 row: the widths the scan kernel knows at compile time
+    return c == 32 || c == 64 || c == 96 || c == 128 || c == 192 || c == 256 || c == 384 || c == 768;
+}
+
+bool prefilter_scan_supported(const rag_index* h, long long nq, int k) {
+    return h->prefilter && h->kind == RAG_KIND_FLAT && nq == 1 && k <= 16 && b16_scan_width(h->ld) && h->n >= 4096;
+}
+
+// after the padded query: [fp32 scan partial lists | bf16 scan partial lists | PRE1 scores | PRE1 rows | flag]
+size_t prefilter_scan_workspace(const rag_index* h, int k) {
+    const size_t blocks = (size_t)scan_blocks(h);
+    return blocks * k * sizeof(u64) + 256 + blocks * PRE1 * sizeof(u64) + 256 + 512 + 512 + 256;
+}
+
+int prefilter_scan_search(rag_index* h, const float* qbuf, int k, float min_score, const uint8_t* mask,
+                          float* D, long long* I, hipStream_t s) {
+    if (int rc = prefilter_sync_rows(h, s)) return rc;
+    const int blocks = scan_blocks(h);
+    const size_t qbytes = ((size_t)h->ld * sizeof(float) + 255) & ~(size_t)255;
+    if (h->ws.bytes < qbytes + prefilter_scan_workspace(h, k))
+        return fail(RAG_ERR_INVALID, "internal: workspace not sized for the bf16 scan");
+    char* w = static_cast<char*>(h->ws.ptr) + qbytes;
+    u64* part32 = reinterpret_cast<u64*>(w);
+    w += (((size_t)blocks * k * sizeof(u64)) + 255) & ~(size_t)255;
+    u64* part16 = reinterpret_cast<u64*>(w);
+    w += (((size_t)blocks * PRE1 * sizeof(u64)) + 255) & ~(size_t)255;
+    float* Dk = reinterpret_cast<float*>(w);
+    long long* Ik = reinterpret_cast<long long*>(w + 512);
+    int* flag = reinterpret_cast<int*>(w + 1024);
+
+    // 1. approximate scan over the bf16 rows, PRE1 best (score, row position)
+    ScanArgs a = {};
+    a.X = reinterpret_cast<const float*>(h->Xb);
+    a.Q = qbuf;
+    a.mask = mask;
+    a.part = part16;
+    a.n = h->n;
+    a.d4 = h->ld / 8;
+    a.k = PRE1;
+    a.ivf_slices = 1;
+    a.grid_y = 1;
+    a.nq_valid = 1;
+    a.b16 = 1;
+    a.nt = ((size_t)h->n * h->ld * 2 > (192ull << 20)) ? 1 : 0;
+    if (int rc = profile_begin(h, s)) return rc;
+    RAG_HIP_CHECK(launch_flat_scan(a, 1, blocks, s));
+    if (int rc = profile_end(h, s)) return rc;
+    MergeArgs m = {};
+    m.keys = part16;
+    m.per_query = (long long)blocks * PRE1;
+    m.k = PRE1;
+    m.cap = merge_cap(m.per_query, PRE1);
+    m.min_score = -FLT_MAX;
+    m.D = Dk;
+    m.I = Ik;
+    RAG_HIP_CHECK(launch_merge_keys(m, 1, s));
+    // 2. exact scores of the kept rows, acceptance test, result
+    MergeArgs fin = {};
+    fin.k = k;
+    fin.min_score = min_score;
+    fin.row_ids = h->ids_dev;
+    fin.id_base = h->id_base;
+    fin.D = D;
+    fin.I = I;
+    VerifyArgs v = {};
+    v.Dk = Dk;
+    v.Ik = Ik;
+    v.X = h->X;
+    v.q = qbuf;
+    v.maxnorm_bits = h->xb_maxnorm;
+    v.ld = h->ld;
+    v.flag = flag;
+    v.fin = fin;
+    hipLaunchKernelGGL(verify_rescore_kernel, dim3(1), dim3(256), 0, s, v);
+    RAG_HIP_CHECK(hipGetLastError());
+    // 3. the fp32 scan, which runs only if the test failed
+    ScanArgs f = {};
+    f.X = h->X;
+    f.Q = qbuf;
+    f.mask = mask;
+    f.part = part32;
+    f.n = h->n;
+    f.d4 = h->ld / 4;
+    f.k = k;
+    f.ivf_slices = 1;
+    f.grid_y = 1;
+    f.nq_valid = 1;
+    f.nt = ((size_t)h->n * h->ld * sizeof(float) > (192ull << 20)) ? 1 : 0;
+    f.run_if = flag;
+    RAG_HIP_CHECK(launch_flat_scan(f, 1, blocks, s));
+    MergeArgs m2 = fin;
+    m2.keys = part32;
+    m2.per_query = (long long)blocks * scan_lists_per_block(k) * k;
+    m2.cap = merge_cap(m2.per_query, k);
+    m2.run_if = flag;
+    RAG_HIP_CHECK(launch_merge_keys(m2, 1, s));
+    h->last_path = "scan-bf16";
     return RAG_OK;
 }
 

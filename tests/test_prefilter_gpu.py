@@ -69,3 +69,33 @@ def test_prefilter_falls_back_when_near_ties_overflow():
     _check(D, I, X, Q, k)
     assert I[0].tolist() == [123] + list(range(5_000, 5_009))
     idx.close()
+
+
+@pytest.mark.parametrize("n,d", [(200_000, 768), (150_000, 1024), (100_000, 256), (60_000, 1536)])
+def test_single_query_bf16_scan_matches_oracle(n, d):
+    """One query: scan of the bf16 rows, fp32 re-score of the 64 kept rows, acceptance test;
+    near-duplicate clusters make some queries fail the test and take the fp32 scan instead."""
+    from rag_amd import DeviceIndex
+    rng = np.random.default_rng(n + d)
+    X = _unit(rng, n, d) * rng.uniform(0.7, 1.4, (n, 1)).astype(np.float32)
+    base = X[77].copy()
+    X[1000:1200] = base + 1e-4 * rng.standard_normal((200, d)).astype(np.float32)    # 200 near ties
+    X[5000:5100] = X[78]                                                              # 100 exact ties
+    Q = _unit(rng, 12, d)
+    Q[0] = base / np.linalg.norm(base)
+    Q[1] = X[78] / np.linalg.norm(X[78])
+    idx = DeviceIndex(d, metric="ip")
+    idx.add(X)
+    idx.set_prefilter(True)
+    mask = (rng.uniform(size=n) < 0.5).astype(np.uint8)
+    for qi in range(12):
+        for k in (1, 10, 16):
+            D, I = idx.search(Q[qi], k)
+            assert idx.last_path == "scan-bf16"
+            _check(D, I, X, Q[qi:qi + 1], k)
+        D, I = idx.search(Q[qi], 10, row_mask=mask, min_score=0.05)
+        _check(D, I, X, Q[qi:qi + 1], 10, row_mask=mask, min_score=0.05)
+    D, I = idx.search(Q[2], 17)                       # k above the supported range: plain fp32 scan
+    assert idx.last_path == "scan"
+    _check(D, I, X, Q[2:3], 17)
+    idx.close()
