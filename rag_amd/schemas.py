@@ -23,8 +23,11 @@ class IndexType(Enum):
 
 @dataclass
 class SearchConfig:
-    """vector_db/search_optimizer.py:43-62.  ``hnsw_config`` / ``quantization_config``
-    are accepted and ignored: every search here is exact (or IVF when asked)."""
+    """vector_db/search_optimizer.py:43-62.  ``hnsw_config`` is accepted and ignored: every
+    search here is exact (or IVF when asked).  A ``quantization_config`` (the reference hands
+    it to the collection, :130, where the server searches a compressed copy and re-scores with
+    the originals) switches on the device-side equivalent: a bf16 copy of the rows searched
+    first, the kept rows re-scored in fp32 -- answers unchanged."""
     dimension: int
     metric: MetricType = MetricType.COSINE
     collection_name: str = "default"

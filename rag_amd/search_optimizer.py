@@ -44,6 +44,8 @@ class HipSearchOptimizer:
         self.logger = logging.getLogger(__name__)
         kind = "ivf" if config.index_type == IndexType.IVF else "flat"
         self.index = DeviceIndex(config.dimension, metric=_METRIC[config.metric], kind=kind, device=config.device)
+        if config.quantization_config is not None and kind == "flat":
+            self.index.set_prefilter(True)
         self.payloads: List[Dict[str, Any]] = []       # row position -> payload
         self.point_ids: List[Any] = []                 # row position -> point id given at upsert
         self._row_of: Dict[Any, int] = {}              # point id -> live row position

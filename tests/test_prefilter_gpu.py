@@ -99,3 +99,18 @@ def test_single_query_bf16_scan_matches_oracle(n, d):
     assert idx.last_path == "scan"
     _check(D, I, X, Q[2:3], 17)
     idx.close()
+
+
+def test_quantization_config_switches_the_first_pass_on():
+    """SearchConfig.quantization_config (search_optimizer.py:51,130) maps to the bf16 first pass."""
+    from rag_amd.schemas import MetricType, SearchConfig
+    from rag_amd.search_optimizer import HipSearchOptimizer
+    rng = np.random.default_rng(3)
+    n, d = 20_000, 256
+    X = _unit(rng, n, d)
+    opt = HipSearchOptimizer(SearchConfig(dimension=d, metric=MetricType.COSINE, collection_name="c",
+                                          quantization_config={"scalar": {"type": "int8"}}))
+    opt.upsert(X, [{"chunk_id": f"c{i}", "document_id": 1} for i in range(n)], list(range(n)))
+    hits = opt.search_sync(X[5].tolist(), limit=3)
+    assert opt.index.last_path == "scan-bf16"
+    assert hits[0][0].chunk_id == "c5" and abs(hits[0][1] - 1.0) < 1e-5
