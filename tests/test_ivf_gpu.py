@@ -73,3 +73,35 @@ def test_ivf_mask_ids_reconstruct_soft_delete():
     D, I = idx.search(Q, 10, nprobe=7)
     _cmp(D, I, *ivf.ivf_search(X, C, Q, 10, 7, ids=ids, row_mask=m2))
     idx.close()
+
+
+def test_row_sharded_ivf_equals_one_index():
+    """Multi-GPU layout of the IVF configuration: every shard holds a slice of every list (same
+    centroids, contiguous row ranges, global ids through id_base); merging the shards' answers
+    gives the answer of one index over all rows."""
+    import torch
+    from rag_amd import DeviceIndex, merge_topk
+    rng = np.random.default_rng(91)
+    n, d, nlist, nprobe, k = 60_000, 256, 64, 6, 10
+    X = _unit(rng, n, d)
+    C = _unit(rng, nlist, d)
+    Q = _unit(rng, 9, d)
+    full = DeviceIndex(d, metric="ip", kind="ivf")
+    full.train_ivf(nlist, centroids=C)
+    full.add(X)
+    Df, If = full.search(Q, k, nprobe=nprobe)
+    parts = []
+    bounds = [0, 17_000, 41_000, n]
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        sh = DeviceIndex(d, metric="ip", kind="ivf")
+        sh.train_ivf(nlist, centroids=C)
+        sh.set_id_base(lo)
+        sh.add(X[lo:hi])
+        parts.append(sh.search(Q, k, nprobe=nprobe))
+        sh.close()
+    D = torch.from_numpy(np.stack([p[0] for p in parts])).cuda()
+    I = torch.from_numpy(np.stack([p[1] for p in parts])).cuda()
+    Dm, Im = merge_topk(D, I)
+    assert np.array_equal(Im.cpu().numpy(), If)
+    assert np.array_equal(Dm.cpu().numpy(), Df)
+    full.close()
