@@ -13,8 +13,16 @@
 //   k <= 1024: a wave-private LDS buffer of 2*pow2(k) keys, bitonic-sorted and cut
 //              to k whenever it fills.
 // A row is a candidate only if its key beats the wave's current k-th key, which
-// after warm-up is rare.  Every wave writes its k keys to `part`; a second, tiny
-// kernel (merge_keys_kernel) merges the P lists per query in LDS.
+// after warm-up is rare.  For k <= 64 the four lists of a block are merged in
+// registers before they are written (one list per block and query in `part`);
+// above, every wave writes its own.  A second, tiny kernel merges the lists per
+// query: merge_keys_small_kernel (k <= 64, register lists and bitonic merges across
+// lanes) or merge_keys_kernel (larger k, bounded by the run heads).
+//
+// Three row sets: the whole corpus (tiles dealt over all waves), the probed lists
+// of an IVF index, or caller-given row ranges (one block per range slice,
+// blockIdx.y = query).  Rows may also be the bf16 copy of the corpus (B16): same
+// kernel, half the bytes, fp32 query and accumulation.
 #include "topk_keys.h"
 #include "kernels.h"
 

@@ -103,18 +103,13 @@ struct GemmArgs {
     int gq;          // placement: query-block groups across the 8 XCDs (0: plain b % nqb_pad decode)
 };
 
-// rare path of the tile epilogue, kept out of line so that the call sites stay small
-#ifndef RAG_GEMM_SCHED
-#define RAG_GEMM_SCHED 1
-#endif
+// cache policy bits of the corpus loads in the narrow shapes (2 = non-temporal)
 #ifndef RAG_GEMM_NARROW_AUX
 #define RAG_GEMM_NARROW_AUX 2
 #endif
-#ifndef RAG_GEMM_PUSH_ATTR
-#define RAG_GEMM_PUSH_ATTR __attribute__((noinline))
-#endif
+// rare path of the tile epilogue, kept out of line so that the call sites stay small
 template <int RT, int QT>
-__device__ RAG_GEMM_PUSH_ATTR void push_candidate(const GemmArgs& a, u64* cand, int* s_cnt, int* s_flag, int ql,
+__device__ __attribute__((noinline)) void push_candidate(const GemmArgs& a, u64* cand, int* s_cnt, int* s_flag, int ql,
                                                          long long row, float sc) {
     constexpr int CAPQ = gemm_capq(RT, QT);
     if (row < a.n && (!a.mask || a.mask[row])) {
@@ -366,7 +361,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
             for (int mi = 0; mi < 2; ++mi) fa[0][mi] = *reinterpret_cast<const f4*>(Ab + mi * 32 * GK + foff[0]);
 #pragma unroll
             for (int nj = 0; nj < NJ; ++nj) fb[0][nj] = *reinterpret_cast<const f4*>(Bb + nj * 32 * GK + foff[0]);
-            if (!B16 && RAG_GEMM_SCHED == 1) __builtin_amdgcn_sched_group_barrier(0x100, READS, 0);
+            if (!B16) __builtin_amdgcn_sched_group_barrier(0x100, READS, 0);
 #pragma unroll
             for (int kb = 0; kb < GK / 8; ++kb) {
                 const int cur = kb & 1, nxt = cur ^ 1;
@@ -393,9 +388,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
                             for (int nj = 0; nj < NJ; ++nj)
                                 acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][mi][s], fb[cur][nj][s], acc[mi][nj], 0, 0, 0);
                 }
-                if (B16) {
-                    // the compiler's own order
-                } else if (RAG_GEMM_SCHED == 1) {
+                if constexpr (!B16) {
                     if (kb + 1 < GK / 8) {
 #pragma unroll
                         for (int j = 0; j < READS; ++j) {
@@ -405,12 +398,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
                         __builtin_amdgcn_sched_group_barrier(0x008, MFMAS - 2 * READS, 0);
                     } else {
                         __builtin_amdgcn_sched_group_barrier(0x008, MFMAS, 0);
-                    }
-                } else if (kb + 1 < GK / 8) {
-#pragma unroll
-                    for (int j = 0; j < READS; ++j) {
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);               // 1 DS read
-                        __builtin_amdgcn_sched_group_barrier(0x008, MFMAS / READS, 0);   // a share of the MFMAs
                     }
                 }
             }
