@@ -254,6 +254,12 @@ extern "C" int rag_index_train_ivf(rag_index_t* h, int nlist, const float* centr
     // centroids are compared as given (never normalised), whatever the index metric
     if (int rc = rag_index_create(h->dim, RAG_METRIC_IP, RAG_KIND_FLAT, h->device, &qz)) return rc;
     if (int rc = rag_index_add(qz, nlist, c, nullptr)) { rag_index_free(qz); return rc; }
+    // assignment of new rows is a large batch against the centroid table: bf16 first pass,
+    // exact fp32 re-score (same lists as the fp32 kernel would give)
+    {
+        const char* e = getenv("RAG_IVF_ASSIGN_BF16");
+        if (!(e && *e == '0') && (qz->ld % 64) == 0) qz->prefilter = 1;
+    }
     v.quantizer = qz;
     v.nlist = nlist;
     int prev = 0;
