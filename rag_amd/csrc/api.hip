@@ -564,11 +564,16 @@ static int search_device_ordered(rag_index* h, int64_t nq, const float* q_dev, i
     const size_t qbytes = ((size_t)nq * h->ld * sizeof(float) + 255) & ~(size_t)255;
     const size_t extra = h->kind == RAG_KIND_FLAT ? flat_search_workspace(h, nq, k) : ivf_search_workspace(h, nq, k, nprobe);
     if (int rc = h->ws.ensure(qbytes + extra)) return rc;
-    // padded (and for COSINE normalised) queries at the start of the workspace
-    RAG_HIP_CHECK(launch_prep_queries(q_dev, nq, h->dim, h->ld, h->metric == RAG_METRIC_COSINE, static_cast<float*>(h->ws.ptr), s));
+    // padded (and for COSINE normalised) queries at the start of the workspace; inner-product
+    // queries that need neither are used where they are (one launch less per search)
+    const float* qbuf = static_cast<const float*>(h->ws.ptr);
+    if (h->metric == RAG_METRIC_IP && h->ld == h->dim && (reinterpret_cast<uintptr_t>(q_dev) & 15) == 0)
+        qbuf = q_dev;
+    else
+        RAG_HIP_CHECK(launch_prep_queries(q_dev, nq, h->dim, h->ld, 0 + (h->metric == RAG_METRIC_COSINE), static_cast<float*>(h->ws.ptr), s));
     if (h->kind == RAG_KIND_IVF)
-        return ivf_search_device(h, nq, static_cast<const float*>(h->ws.ptr), k, min_score, nprobe, mask, D_dev, I, s);
-    return flat_search_prepared(h, nq, static_cast<const float*>(h->ws.ptr), k, min_score, mask, D_dev, I, s);
+        return ivf_search_device(h, nq, qbuf, k, min_score, nprobe, mask, D_dev, I, s);
+    return flat_search_prepared(h, nq, qbuf, k, min_score, mask, D_dev, I, s);
 }
 
 int rag_index_search(rag_index_t* h, int64_t nq, const float* q, int k, float min_score, int nprobe,
