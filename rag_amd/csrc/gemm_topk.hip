@@ -61,6 +61,11 @@ namespace rag {
 
 int merge_cap(long long per_query, int k);
 
+static int env_int_g(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 
@@ -101,6 +106,16 @@ struct GemmArgs {
     int nqb_pad;     // query blocks rounded up for the XCD-friendly decode
     int S;           // row ranges
     int gq;          // placement: query-block groups across the 8 XCDs (0: plain b % nqb_pad decode)
+    // list-major IVF scan (TASKS): a work item = up to QT queries that probe one list
+    const int* total_tasks;        // device: number of work items
+    const int* task_list;          // [tasks] list of the work item
+    const int* task_begin;         // [nlist] first work item of a list
+    const int* pair_begin;         // [nlist] first (query, probe) pair of a list
+    const int* pair_cnt;           // [nlist] pairs of a list
+    const int* pair_q;             // [pairs] query of a pair, grouped by list
+    const int* pair_slot;          // [pairs] where the pair's k keys go in part (slot * k)
+    const long long* list_begin;   // [nlist + 1] rows of a list (storage order)
+    const long long* row_alias;    // storage position -> row number reported in keys (NULL: identity)
 };
 
 // cache policy bits of the corpus loads in the narrow shapes (2 = non-temporal)
@@ -110,11 +125,11 @@ struct GemmArgs {
 // rare path of the tile epilogue, kept out of line so that the call sites stay small
 template <int RT, int QT>
 __device__ __attribute__((noinline)) void push_candidate(const GemmArgs& a, u64* cand, int* s_cnt, int* s_flag, int ql,
-                                                         long long row, float sc) {
+                                                         long long row, long long row_hi, float sc) {
     constexpr int CAPQ = gemm_capq(RT, QT);
-    if (row < a.n && (!a.mask || a.mask[row])) {
+    if (row < row_hi && (!a.mask || a.mask[row])) {
         const int pos = atomicAdd(&s_cnt[ql], 1);
-        cand[(size_t)ql * CAPQ + pos] = make_key(sc, (uint32_t)row);
+        cand[(size_t)ql * CAPQ + pos] = make_key(sc, (uint32_t)(a.row_alias ? a.row_alias[row] : row));
         if (pos + 1 > gemm_trig(RT, QT)) *s_flag = 1;       // compact before the next tile can overflow it
     }
 }
@@ -173,13 +188,13 @@ __device__ __forceinline__ void compact_queries(u64* scratch, u64* cand, int* s_
 // first query (within the block) of this wave's NJ * 32.
 template <int RT, int QT, int NJ>
 __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f16v (&acc)[2][NJ], u64* cand, float* s_thr, int* s_cnt,
-                                              int* s_flag, int q0, long long rbase, int qbase, int l31, int h) {
+                                              int* s_flag, int m_valid, long long rbase, long long row_hi, int qbase, int l31, int h) {
     float thr[NJ];
     bool hit = false;
 #pragma unroll
     for (int nj = 0; nj < NJ; ++nj) {
         const int ql = qbase + nj * 32 + l31;
-        thr[nj] = (q0 + ql) < a.nq ? s_thr[ql] : INFINITY;
+        thr[nj] = ql < m_valid ? s_thr[ql] : INFINITY;
         float m = -INFINITY;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
@@ -197,7 +212,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f16v (&acc)[2][
                 for (int r = 0; r < 16; ++r) {
                     const float sc = acc[mi][nj][r];
                     if (sc > thr[nj])
-                        push_candidate<RT, QT>(a, cand, s_cnt, s_flag, ql, rbase + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, sc);
+                        push_candidate<RT, QT>(a, cand, s_cnt, s_flag, ql, rbase + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, row_hi, sc);
                 }
             }
         }
@@ -206,8 +221,9 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f16v (&acc)[2][
 
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 
-template <int RT, int QT, int NW, bool B16>
+template <int RT, int QT, int NW, bool B16, bool TASKS = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(GemmArgs a) {
+    static_assert(!TASKS || (!B16 && QT == 32), "work items of the list-major scan use the 256 x 32 fp32 shape");
     constexpr int NT = NW * 64;              // threads
     constexpr int WM = RT / 64;              // waves along the corpus rows
     constexpr int WQ = NW / WM;              // waves along the queries
@@ -242,26 +258,44 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
     const int h = lane >> 5;
 
     const int b = blockIdx.x;
-    int qb, sp;
-    if (a.gq > 0) {
-        // XCD x = b % 8 owns query-block group x % gq and row-range group x / gq; inside the XCD
-        // consecutive workgroups take different query blocks of the same row range
-        const int xcd = b & 7, j = b >> 3;
-        const int m = a.nqb_pad / a.gq, r = a.S / (8 / a.gq);
-        qb = (xcd % a.gq) * m + (j % m);
-        sp = (xcd / a.gq) * r + (j / m);
-    } else {
-        qb = b % a.nqb_pad;
-        sp = b / a.nqb_pad;
-    }
-    if (qb >= a.nqb) return;
-    const int q0 = qb * QT;
     const int k = a.k;
     // a K step is 128 bytes of every row: 32 floats, or 64 bf16
     const int KT = B16 ? a.ld / (2 * GK) : a.ld / GK;
-    const long long t_begin = a.ntiles * sp / a.S;
-    const long long t_end = a.ntiles * (sp + 1) / a.S;
     u64* cand = a.cand + (size_t)b * QT * CAPQ;
+    const int ntasks = TASKS ? *a.total_tasks : 1;
+  for (int task = TASKS ? b : 0; task < ntasks; task += TASKS ? (int)gridDim.x : 1) {
+    // ---- the work item: which queries, which rows, where the keys go ------------------
+    int q0 = 0, sp = 0, m_valid, p0 = 0;
+    long long row_lo = 0, row_hi = a.n, t_begin, t_end;
+    if constexpr (TASKS) {
+        const int lst = a.task_list[task];
+        const int g = task - a.task_begin[lst];
+        p0 = a.pair_begin[lst] + g * QT;
+        m_valid = a.pair_cnt[lst] - g * QT;
+        m_valid = m_valid < QT ? m_valid : QT;
+        row_lo = a.list_begin[lst];
+        row_hi = a.list_begin[lst + 1];
+        t_begin = 0;
+        t_end = (row_hi - row_lo + RT - 1) / RT;
+    } else {
+        int qb;
+        if (a.gq > 0) {
+            // XCD x = b % 8 owns query-block group x % gq and row-range group x / gq; inside the XCD
+            // consecutive workgroups take different query blocks of the same row range
+            const int xcd = b & 7, j = b >> 3;
+            const int m = a.nqb_pad / a.gq, r = a.S / (8 / a.gq);
+            qb = (xcd % a.gq) * m + (j % m);
+            sp = (xcd / a.gq) * r + (j / m);
+        } else {
+            qb = b % a.nqb_pad;
+            sp = b / a.nqb_pad;
+        }
+        if (qb >= a.nqb) return;
+        q0 = qb * QT;
+        m_valid = a.nq - q0 < QT ? a.nq - q0 : QT;
+        t_begin = a.ntiles * sp / a.S;
+        t_end = a.ntiles * (sp + 1) / a.S;
+    }
 
     for (int i = tid; i < QT; i += NT) {
         s_thr[i] = -INFINITY;
@@ -290,15 +324,20 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
 #pragma unroll
     for (int i = 0; i < BPW; ++i) {
         const int brow = (wv * BPW + i) * 8 + (lane >> 3);
-        int qr = q0 + brow;
-        qr = qr < a.nq ? qr : a.nq - 1;
+        int qr;
+        if constexpr (TASKS) {
+            qr = a.pair_q[p0 + (brow < m_valid ? brow : m_valid - 1)];
+        } else {
+            qr = q0 + brow;
+            qr = qr < a.nq ? qr : a.nq - 1;
+        }
         qp[i] = Q4 + (long long)qr * ld4 + ((lane & 7) ^ ((brow >> 1) & 7));
     }
     auto set_tile = [&](long long t) {
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
-            long long r = t * RT + arow[i];
-            r = r < a.n ? r : a.n - 1;
+            long long r = row_lo + t * RT + arow[i];
+            r = r < row_hi ? r : row_hi - 1;
             xp[i] = X4 + r * ld4 + achunk[i];
         }
     };
@@ -413,7 +452,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
             if (keep == 123.456f) s_thr[0] = keep;      // keeps the accumulators live
             continue;
         }
-        tile_epilogue<RT, QT, NJ>(a, acc, cand, s_thr, s_cnt, s_flag, q0, t * RT + wm * 64, wq * NJ * 32, l31, h);
+        tile_epilogue<RT, QT, NJ>(a, acc, cand, s_thr, s_cnt, s_flag, m_valid, row_lo + t * RT + wm * 64, row_hi, wq * NJ * 32, l31, h);
     }
 
     // ---- final: every query's k best keys of this row range -> part ---------------------
@@ -421,12 +460,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
     {
         u64* scratch = reinterpret_cast<u64*>(As) + wave * CAPQ2;
         for (int ql = wave; ql < QT; ql += NW) {
-            if (q0 + ql >= a.nq) continue;
+            if (ql >= m_valid) continue;
             const int c = s_cnt[ql];
             const int n2 = pow2_ceil(c > k ? c : k);
             for (int i = lane; i < n2; i += 64) scratch[i] = (i < c) ? cand[(size_t)ql * CAPQ + i] : KEY_EMPTY;
             bitonic_sort_desc_lds(scratch, n2, lane, 64, SyncWave());
-            u64* out = a.part + ((size_t)(q0 + ql) * a.S + sp) * a.outc;
+            u64* out = TASKS ? a.part + (size_t)a.pair_slot[p0 + ql] * k
+                             : a.part + ((size_t)(q0 + ql) * a.S + sp) * a.outc;
             if constexpr (B16) {
                 int keep = c;
                 if (c >= k) keep = count_above(scratch, c, key_score(scratch[k - 1]) - s_margin[ql], lane);
@@ -441,6 +481,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
             SyncWave()();
         }
     }
+    if constexpr (TASKS) __syncthreads();      // the next work item re-initialises the LDS state
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -578,10 +620,6 @@ __global__ void queries_to_bf16_kernel(const float* Q, int ld, const int* maxnor
     if (lane == 63) margin[q] = 2.f * PREF_ERR * __int_as_float(*maxnorm_bits) * sqrtf(ss) * 1.0001f + 1e-30f;
 }
 
-static int env_int_g(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
 
 bool gemm_topk_supported(const rag_index* h, long long nq, int k) {
     static const int min_nq = env_int_g("RAG_GEMM_MIN_NQ", 5);
@@ -766,6 +804,156 @@ int gemm_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float
     if (int rc2 = profile_end(h, s)) return rc2;
     RAG_HIP_CHECK(launch_merge_keys(m, nq, s));
     h->last_path = "gemm";
+    return RAG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// List-major IVF scan for large batches.  After the coarse step every query has nprobe lists; with
+// many queries a list is probed by several of them, and scanning per query would read it once for
+// each.  Here the (query, probe) pairs are grouped by list on the device, a work item is "up to 32
+// queries of one list", and the 256 x 32 MFMA shape scores the list's rows against them: a list
+// is read once per 32 probing queries.  Every pair's k keys go to its own slot (query * nprobe +
+// probe), and the usual merge reduces a query's nprobe slots.
+__global__ void lm_count_kernel(const long long* lists, long long npairs, int* cnt) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < npairs; i += (long long)gridDim.x * blockDim.x) {
+        const long long l = lists[i];
+        if (l >= 0) atomicAdd(&cnt[l], 1);
+    }
+}
+// one workgroup: exclusive scans of the pair counts and of the work-item counts, work-item table
+__global__ __launch_bounds__(1024) void lm_plan_kernel(const int* cnt, int nlist, const long long* list_begin, int* pair_begin,
+                                                       int* task_begin, int* task_list, int* total_tasks) {
+    __shared__ int sp[1024], st[1024];
+    __shared__ int carry_p, carry_t;
+    const int tid = threadIdx.x;
+    if (tid == 0) { carry_p = 0; carry_t = 0; }
+    __syncthreads();
+    for (int base = 0; base < nlist; base += 1024) {
+        const int l = base + tid;
+        int c = 0, t = 0;
+        if (l < nlist) {
+            c = cnt[l];
+            t = (list_begin[l + 1] > list_begin[l]) ? (c + 31) / 32 : 0;     // an empty list needs no work
+        }
+        sp[tid] = c;
+        st[tid] = t;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {          // inclusive scan
+            const int ap = tid >= off ? sp[tid - off] : 0, at = tid >= off ? st[tid - off] : 0;
+            __syncthreads();
+            sp[tid] += ap;
+            st[tid] += at;
+            __syncthreads();
+        }
+        const int pb = carry_p + sp[tid] - c, tb = carry_t + st[tid] - t;
+        if (l < nlist) {
+            pair_begin[l] = pb;
+            task_begin[l] = tb;
+            for (int g = 0; g < t; ++g) task_list[tb + g] = l;
+        }
+        __syncthreads();
+        if (tid == 1023) { carry_p += sp[1023]; carry_t += st[1023]; }
+        __syncthreads();
+    }
+    if (tid == 0) *total_tasks = carry_t;
+}
+__global__ void lm_fill_kernel(const long long* lists, long long npairs, int nprobe, const int* pair_begin, int* fill,
+                               int* pair_q, int* pair_slot) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < npairs; i += (long long)gridDim.x * blockDim.x) {
+        const long long l = lists[i];
+        if (l < 0) continue;
+        const int pos = pair_begin[l] + atomicAdd(&fill[l], 1);
+        pair_q[pos] = (int)(i / nprobe);
+        pair_slot[pos] = (int)i;
+    }
+}
+
+constexpr int LM_GRID = 512;      // persistent workgroups of the list-major scan (2 per CU)
+
+static size_t lm_align(size_t b) { return (b + 255) & ~(size_t)255; }
+
+bool ivf_listmajor_supported(const rag_index* h, long long nq, int k, int nprobe) {
+    static const int on = env_int_g("RAG_IVF_LISTMAJOR", 1);
+    const long long npairs = nq * (long long)nprobe;
+    return on && k <= GEMM_MAX_K && (h->ld % GK) == 0 && npairs >= 2LL * h->ivf.nlist && npairs < (1LL << 30);
+}
+
+// bytes after the padded queries: [4 x nlist ints | total | work-item table | pair_q | pair_slot | cand | part]
+size_t ivf_listmajor_workspace(const rag_index* h, long long nq, int k, int nprobe) {
+    const size_t nlist = (size_t)h->ivf.nlist, npairs = (size_t)nq * nprobe;
+    return 4 * lm_align(nlist * 4) + 256 + lm_align((std::min(nlist, npairs) + npairs / 32 + 64) * 4) + 2 * lm_align(npairs * 4) +
+           (size_t)LM_GRID * 32 * gemm_capq(256, 32) * sizeof(u64) + lm_align(npairs * k * sizeof(u64));
+}
+
+int ivf_listmajor_scan(rag_index* h, long long nq, const float* qbuf, int k, float min_score, int nprobe,
+                       const long long* coarse_lists, const uint8_t* packed_mask, float* D, long long* I, hipStream_t s) {
+    const IvfState& v = h->ivf;
+    const size_t nlist = (size_t)v.nlist, npairs = (size_t)nq * nprobe;
+    const size_t qbytes = ((size_t)nq * h->ld * sizeof(float) + 255) & ~(size_t)255;
+    if (h->ws.bytes < qbytes + ivf_listmajor_workspace(h, nq, k, nprobe))
+        return fail(RAG_ERR_INVALID, "internal: workspace not sized for the list-major scan");
+    char* w = static_cast<char*>(h->ws.ptr) + qbytes;
+    int* cnt = reinterpret_cast<int*>(w);                w += lm_align(nlist * 4);
+    int* fill = reinterpret_cast<int*>(w);               w += lm_align(nlist * 4);
+    int* pair_begin = reinterpret_cast<int*>(w);         w += lm_align(nlist * 4);
+    int* task_begin = reinterpret_cast<int*>(w);         w += lm_align(nlist * 4);
+    int* total = reinterpret_cast<int*>(w);              w += 256;
+    int* task_list = reinterpret_cast<int*>(w);          w += lm_align((std::min(nlist, npairs) + npairs / 32 + 64) * 4);
+    int* pair_q = reinterpret_cast<int*>(w);             w += lm_align(npairs * 4);
+    int* pair_slot = reinterpret_cast<int*>(w);          w += lm_align(npairs * 4);
+    u64* cand = reinterpret_cast<u64*>(w);               w += (size_t)LM_GRID * 32 * gemm_capq(256, 32) * sizeof(u64);
+    u64* part = reinterpret_cast<u64*>(w);
+    RAG_HIP_CHECK(hipMemsetAsync(cnt, 0, 2 * lm_align(nlist * 4), s));          // cnt and fill
+    RAG_HIP_CHECK(hipMemsetAsync(part, 0, npairs * k * sizeof(u64), s));        // pairs without rows stay empty
+    const int pb = (int)std::min<size_t>((npairs + 255) / 256, 4096);
+    hipLaunchKernelGGL(lm_count_kernel, dim3(pb), dim3(256), 0, s, coarse_lists, (long long)npairs, cnt);
+    hipLaunchKernelGGL(lm_plan_kernel, dim3(1), dim3(1024), 0, s, cnt, (int)nlist, v.list_begin_dev, pair_begin, task_begin, task_list, total);
+    hipLaunchKernelGGL(lm_fill_kernel, dim3(pb), dim3(256), 0, s, coarse_lists, (long long)npairs, nprobe, pair_begin, fill, pair_q, pair_slot);
+    RAG_HIP_CHECK(hipGetLastError());
+    GemmArgs a = {};
+    a.X = h->X;
+    a.Q = qbuf;
+    a.mask = packed_mask;
+    a.cand = cand;
+    a.part = part;
+    a.n = h->n;
+    a.nq = (int)nq;
+    a.ld = h->ld;
+    a.k = k;
+    a.outc = k;
+    a.total_tasks = total;
+    a.task_list = task_list;
+    a.task_begin = task_begin;
+    a.pair_begin = pair_begin;
+    a.pair_cnt = cnt;
+    a.pair_q = pair_q;
+    a.pair_slot = pair_slot;
+    a.list_begin = v.list_begin_dev;
+    a.row_alias = v.orig_dev;
+    if (int rc = profile_begin(h, s)) return rc;
+    {
+        constexpr size_t lds = (size_t)(2 * (256 + 32) * GK) * sizeof(float) + 32 * 8 + 16;
+        static bool attr_set[64] = {};
+        if (!attr_set[h->device & 63]) {
+            RAG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_topk_kernel<256, 32, 4, false, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set[h->device & 63] = true;
+        }
+        hipLaunchKernelGGL((gemm_topk_kernel<256, 32, 4, false, true>), dim3(LM_GRID), dim3(256), lds, s, a);
+        RAG_HIP_CHECK(hipGetLastError());
+    }
+    if (int rc = profile_end(h, s)) return rc;
+    MergeArgs m = {};
+    m.keys = part;
+    m.per_query = (long long)nprobe * k;
+    m.k = k;
+    m.cap = merge_cap(m.per_query, k);
+    m.min_score = min_score;
+    m.row_ids = h->ids_dev;
+    m.id_base = h->id_base;
+    m.D = D;
+    m.I = I;
+    RAG_HIP_CHECK(launch_merge_keys(m, nq, s));
     return RAG_OK;
 }
 

@@ -59,10 +59,16 @@ static long long ivf_slices(const rag_index* h, long long nq, int nprobe) {
     return slices < 1 ? 1 : slices;
 }
 
+bool ivf_listmajor_supported(const rag_index* h, long long nq, int k, int nprobe);            // gemm_topk.hip
+size_t ivf_listmajor_workspace(const rag_index* h, long long nq, int k, int nprobe);
+int ivf_listmajor_scan(rag_index* h, long long nq, const float* qbuf, int k, float min_score, int nprobe,
+                       const long long* coarse_lists, const uint8_t* packed_mask, float* D, long long* I, hipStream_t s);
+
 // bytes the list scan needs in h->ws after the padded queries
 size_t ivf_search_workspace(const rag_index* h, long long nq, int k, int nprobe) {
     if (nprobe > h->ivf.nlist) nprobe = h->ivf.nlist;
     if (nprobe < 1) nprobe = 1;
+    if (ivf_listmajor_supported(h, nq, k, nprobe)) return ivf_listmajor_workspace(h, nq, k, nprobe);
     const long long waves = (long long)nprobe * ivf_slices(h, nq, nprobe) * 4;
     return (size_t)std::min(nq, IVF_QCHUNK) * waves * k * sizeof(u64);
 }
@@ -187,6 +193,11 @@ int ivf_search_device(rag_index* h, long long nq, const float* qbuf, int k, floa
         RAG_HIP_CHECK(hipGetLastError());
     }
     // --- list scan ------------------------------------------------------------------------------
+    if (ivf_listmajor_supported(h, nq, k, nprobe)) {
+        if (int rc = ivf_listmajor_scan(h, nq, qbuf, k, min_score, nprobe, cI, pmask, D, I, s)) return rc;
+        h->last_path = "ivf-listmajor";
+        return RAG_OK;
+    }
     const long long slices = ivf_slices(h, nq, nprobe);
     const int gx = (int)(nprobe * slices);
     const size_t qbytes = ((size_t)nq * h->ld * sizeof(float) + 255) & ~(size_t)255;

@@ -1,2 +1,2 @@
 set -e
-for gq in 8 4 2 1; do export RAG_GEMM_GQ=$gq PREFILTER=1 NQ=4096 STEPS=3 WARMUP=2; echo -n "gq=$gq "; timeout -k 10 120 python3 scripts/tune_scan.py 2>&1 | grep kernel_ms | sed -e 's/blocks=.*path=/path=/'; done
+for mt in 16 8 4 2; do export RAG_SCAN_MIN_TILES=$mt; echo "min_tiles=$mt"; timeout -k 10 200 python3 scripts/bench_small.py 2>&1 | grep -v amdgpu | head -2; done

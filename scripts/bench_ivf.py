@@ -33,12 +33,12 @@ if clustered:
         a = torch.randint(0, nlist, (c,), device=dev, generator=g)
         X[r0:r0 + c] = torch.nn.functional.normalize(
             C[a] + (0.6 / dim ** 0.5) * torch.randn(c, dim, device=dev, generator=g), dim=1)
-    pick = torch.randint(0, rows, (256,), device=dev, generator=g)
-    Q = torch.nn.functional.normalize(X[pick] + (0.3 / dim ** 0.5) * torch.randn(256, dim, device=dev, generator=g), dim=1)
+    pick = torch.randint(0, rows, (4096,), device=dev, generator=g)
+    Q = torch.nn.functional.normalize(X[pick] + (0.3 / dim ** 0.5) * torch.randn(4096, dim, device=dev, generator=g), dim=1)
     cent = C.cpu().numpy()
 else:
     X = make_corpus(torch, 0, rows, dim, dev)
-    Q = make_queries(torch, 256, dim, dev)
+    Q = make_queries(torch, 4096, dim, dev)
     cent = X[torch.arange(0, rows, rows // nlist, device=dev)[:nlist]].cpu().numpy()
 ivf = DeviceIndex(dim, metric="ip", kind="ivf")
 ivf.train_ivf(nlist, centroids=cent)
@@ -55,7 +55,7 @@ t_pack = time.perf_counter() - t0
 flat = DeviceIndex(dim, metric="ip")
 flat.adopt(X)
 out = {"clustered_corpus": clustered, "rows": rows, "dim": dim, "nlist": nlist, "nprobe": nprobe, "add_assign_s": t_add, "first_search_pack_s": t_pack}
-for nq, steps in ((1, 50), (256, 5)):
+for nq, steps in ((1, 50), (256, 5), (4096, 3)):
     ivf.profile(True)
     ivf.search(Q[:nq], k, nprobe=nprobe)
     torch.cuda.synchronize()
@@ -72,5 +72,5 @@ for nq, steps in ((1, 50), (256, 5)):
     scanned = nq * nprobe * (rows / nlist) * dim * 4          # expected bytes per batch (uniform lists)
     out[f"batch_{nq}"] = {"qps": nq * steps / dt, "ms_per_batch": dt / steps * 1e3,
                           "scan_kernel_ms": ms / max(launches, 1), "scan_GBps_expected_bytes": scanned / (ms / max(launches, 1) * 1e-3) / 1e9,
-                          "recall_at_10_vs_exhaustive": float(hit)}
+                          "recall_at_10_vs_exhaustive": float(hit), "path": ivf.last_path}
 print(json.dumps(out))

@@ -21,7 +21,8 @@ def _cmp(D, I, Dr, Ir):
 
 @pytest.mark.parametrize("n,d,nlist,nprobe,nq,k", [
     (60_000, 128, 64, 8, 1, 10), (60_000, 128, 64, 8, 40, 10), (30_000, 768, 128, 16, 3, 10),
-    (20_000, 384, 32, 32, 5, 100), (5_000, 100, 16, 4, 2, 10), (80_000, 64, 256, 64, 200, 5)])
+    (20_000, 384, 32, 32, 5, 100), (5_000, 100, 16, 4, 2, 10), (80_000, 64, 256, 64, 200, 5),
+    (50_000, 256, 128, 16, 700, 10), (40_000, 768, 64, 4, 1000, 64)])
 def test_ivf_matches_oracle(n, d, nlist, nprobe, nq, k):
     from oracle import ivf
     from rag_amd import DeviceIndex
@@ -36,7 +37,9 @@ def test_ivf_matches_oracle(n, d, nlist, nprobe, nq, k):
     _cmp(D0, I0, *ivf.ivf_search(X[: n // 3], C, Q, k, nprobe))
     idx.add(X[n // 3:])
     D, I = idx.search(Q, k, nprobe=nprobe)
-    assert idx.last_path == "ivf"
+    # batches in which lists are probed by several queries take the list-major MFMA scan
+    listmajor = nq * nprobe >= 2 * nlist and k <= 64 and d % 32 == 0
+    assert idx.last_path == ("ivf-listmajor" if listmajor else "ivf")
     _cmp(D, I, *ivf.ivf_search(X, C, Q, k, nprobe))
     # nprobe = nlist degenerates to the exhaustive answer
     from oracle import flat
@@ -64,6 +67,10 @@ def test_ivf_mask_ids_reconstruct_soft_delete():
     mask = (rng.uniform(size=n) < 0.4).astype(np.uint8)
     D, I = idx.search(Q, 10, nprobe=7, row_mask=mask, min_score=0.02)
     _cmp(D, I, *ivf.ivf_search(X, C, Q, 10, 7, ids=ids, row_mask=mask, min_score=0.02))
+    Qb = _unit(rng, 300, d)                           # a batch large enough for the list-major scan
+    D, I = idx.search(Qb, 10, nprobe=7, row_mask=mask, min_score=0.02)
+    assert idx.last_path == "ivf-listmajor"
+    _cmp(D, I, *ivf.ivf_search(X, C, Qb, 10, 7, ids=ids, row_mask=mask, min_score=0.02))
     R = idx.reconstruct([0, 123, n - 1])
     assert np.array_equal(R, X[[0, 123, n - 1]])
     gone = np.arange(0, n, 3)
