@@ -116,15 +116,21 @@ struct GemmArgs {
     const int* pair_slot;          // [pairs] where the pair's k keys go in part (slot * k)
     const long long* list_begin;   // [nlist + 1] rows of a list (storage order)
     const long long* row_alias;    // storage position -> row number reported in keys (NULL: identity)
+    // fp32 pass: the best k-th score any row range has reached so far, per query (ordered-float bits,
+    // 0 = none yet).  Every workgroup of a query raises it when it compacts and reads it once per tile:
+    // a row scoring below another range's k-th best cannot be in the answer.
+    unsigned int* gthr;
 };
 
 // cache policy bits of the corpus loads in the narrow shapes (2 = non-temporal)
 #ifndef RAG_GEMM_NARROW_AUX
 #define RAG_GEMM_NARROW_AUX 2
 #endif
-// rare path of the tile epilogue, kept out of line so that the call sites stay small
+// rare path of the tile epilogue.  Inlined on purpose: as an out-of-line call (accumulators and
+// thresholds live across it, partial exec mask) it was no faster and, once register pressure rose,
+// returned wrong candidates now and then.
 template <int RT, int QT>
-__device__ __attribute__((noinline)) void push_candidate(const GemmArgs& a, u64* cand, int* s_cnt, int* s_flag, int ql,
+__device__ __forceinline__ void push_candidate(const GemmArgs& a, u64* cand, int* s_cnt, int* s_flag, int ql,
                                                          long long row, long long row_hi, float sc) {
     constexpr int CAPQ = gemm_capq(RT, QT);
     if (row < row_hi && (!a.mask || a.mask[row])) {
@@ -152,7 +158,7 @@ __device__ __forceinline__ int count_above(const u64* sorted, int n, float thr, 
 // tighten the threshold
 template <int RT, int QT, int NW, bool B16>
 __device__ __forceinline__ void compact_queries(u64* scratch, u64* cand, int* s_cnt, float* s_thr, const float* s_margin,
-                                                int* overflow, int k, int wave, int lane) {
+                                                int* overflow, unsigned int* gthr, int k, int wave, int lane) {
     constexpr int CAPQ = gemm_capq(RT, QT);
     constexpr int TRIG = gemm_trig(RT, QT);
     for (int ql = wave; ql < QT; ql += NW) {
@@ -176,7 +182,10 @@ __device__ __forceinline__ void compact_queries(u64* scratch, u64* cand, int* s_
         for (int i = lane; i < keep; i += 64) cand[(size_t)ql * CAPQ + i] = scratch[i];
         if (lane == 0) {
             s_cnt[ql] = keep;
-            if (c >= k) s_thr[ql] = thr;
+            if (c >= k) {
+                s_thr[ql] = thr;
+                if (!B16 && gthr) atomicMax(&gthr[ql], f32_ordered(thr));
+            }
         }
         SyncWave()();
     }
@@ -188,7 +197,8 @@ __device__ __forceinline__ void compact_queries(u64* scratch, u64* cand, int* s_
 // first query (within the block) of this wave's NJ * 32.
 template <int RT, int QT, int NJ>
 __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f16v (&acc)[2][NJ], u64* cand, float* s_thr, int* s_cnt,
-                                              int* s_flag, int m_valid, long long rbase, long long row_hi, int qbase, int l31, int h) {
+                                              int* s_flag, int m_valid, long long rbase, long long row_hi, int qbase, int l31, int h,
+                                              const float (&tg)[NJ]) {
     float thr[NJ];
     bool hit = false;
 #pragma unroll
@@ -200,7 +210,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f16v (&acc)[2][
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[mi][nj][r]);
-        hit |= m > thr[nj];
+        hit |= m > thr[nj] && m >= tg[nj];      // a tie with another range's k-th best may still win on row number
     }
     if (__ballot(hit) != 0ull) {
 #pragma unroll
@@ -211,7 +221,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f16v (&acc)[2][
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float sc = acc[mi][nj][r];
-                    if (sc > thr[nj])
+                    if (sc > thr[nj] && sc >= tg[nj])
                         push_candidate<RT, QT>(a, cand, s_cnt, s_flag, ql, rbase + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, row_hi, sc);
                 }
             }
@@ -372,14 +382,31 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
             for (int nj = 0; nj < NJ; ++nj)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][nj][r] = 0.f;
+        // the other row ranges' progress on this lane's queries: requested at the start of the last
+        // K step, used after it (the latency hides behind that step's MFMAs)
+        float tg[NJ];
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj) tg[nj] = -INFINITY;
         for (int kt = 0; kt < KT; ++kt, buf ^= 1) {
             if (!(DIAG & 4) || (t == t_begin && kt < 2))
                 __syncthreads();     // stage `buf` is complete (the LDS-DMA in flight is drained here too)
+            if constexpr (!B16 && !TASKS) {
+                if (kt == KT - 1 && a.gthr) {
+#pragma unroll
+                    for (int nj = 0; nj < NJ; ++nj) {
+                        const int ql = wq * NJ * 32 + nj * 32 + l31;
+                        if (ql < m_valid) {
+                            const unsigned int o = __hip_atomic_load(&a.gthr[q0 + ql], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (o != 0u) tg[nj] = ordered_f32(o);
+                        }
+                    }
+                }
+            }
             // a candidate buffer filled up during the previous tile's epilogue: every wave has
             // passed the barrier above, so the flag is stable and stage buf^1 is idle
             if (kt == 0 && *s_flag != 0) {
                 compact_queries<RT, QT, NW, B16>(reinterpret_cast<u64*>(As + (buf ^ 1) * TILEA) + wave * CAPQ2, cand, s_cnt, s_thr, s_margin,
-                                                 a.overflow, k, wave, lane);
+                                                 a.overflow, (!B16 && !TASKS && a.gthr) ? a.gthr + q0 : nullptr, k, wave, lane);
                 __syncthreads();
                 if (tid == 0) *s_flag = 0;
             }
@@ -452,7 +479,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
             if (keep == 123.456f) s_thr[0] = keep;      // keeps the accumulators live
             continue;
         }
-        tile_epilogue<RT, QT, NJ>(a, acc, cand, s_thr, s_cnt, s_flag, m_valid, row_lo + t * RT + wm * 64, row_hi, wq * NJ * 32, l31, h);
+        tile_epilogue<RT, QT, NJ>(a, acc, cand, s_thr, s_cnt, s_flag, m_valid, row_lo + t * RT + wm * 64, row_hi, wq * NJ * 32, l31, h, tg);
     }
 
     // ---- final: every query's k best keys of this row range -> part ---------------------
@@ -633,6 +660,7 @@ struct GemmPlan {
     size_t cand_bytes, part_bytes;
     bool pref;                                   // bf16 first pass + fp32 re-scoring
     size_t qb_bytes, margin_bytes, part16_bytes; // its extra workspace (then 256 bytes for the flag)
+    size_t gthr_bytes;                           // shared per-query thresholds of the fp32 pass
 };
 
 // tile shape, (query blocks, padded query blocks, row ranges) and workspace for a batch of nq queries
@@ -666,6 +694,7 @@ static GemmPlan gemm_plan(const rag_index* h, long long nq, int k) {
     if (gq_env == 0) p.gq = 0;
     p.cand_bytes = (size_t)p.nqb_pad * p.S * p.QT * gemm_capq(p.RT, p.QT) * sizeof(u64);
     p.part_bytes = ((size_t)nq * p.S * k * sizeof(u64) + 255) & ~(size_t)255;
+    p.gthr_bytes = ((size_t)nq * sizeof(unsigned int) + 255) & ~(size_t)255;
     // the bf16 first pass pays off where the batch is MFMA-bound: the 256 x 256 shape
     p.pref = h->prefilter && p.QT == 256 && (h->ld % (2 * GK)) == 0 && (long long)p.S * PREF_OUTC <= 16384;
     p.qb_bytes = p.pref ? (((size_t)nq * h->ld * 2 + 255) & ~(size_t)255) : 0;
@@ -677,7 +706,7 @@ static GemmPlan gemm_plan(const rag_index* h, long long nq, int k) {
 // bytes of workspace the gemm path needs after the padded queries
 size_t gemm_topk_workspace(const rag_index* h, long long nq, int k) {
     const GemmPlan p = gemm_plan(h, nq, k);
-    return p.cand_bytes + p.part_bytes + p.qb_bytes + p.margin_bytes + p.part16_bytes + (p.pref ? 256 : 0);
+    return p.cand_bytes + p.part_bytes + p.gthr_bytes + p.qb_bytes + p.margin_bytes + p.part16_bytes + (p.pref ? 256 : 0);
 }
 
 template <int RT, int QT, int NW, bool B16 = false>
@@ -743,6 +772,11 @@ int gemm_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float
     a.Q = qbuf;
     a.cand = reinterpret_cast<u64*>(w);
     a.part = reinterpret_cast<u64*>(w + p.cand_bytes);
+    static const int share_thr = env_int_g("RAG_GEMM_SHARE_THR", 1);
+    if (share_thr && p.S > 1) {
+        a.gthr = reinterpret_cast<unsigned int*>(w + p.cand_bytes + p.part_bytes);
+        RAG_HIP_CHECK(hipMemsetAsync(a.gthr, 0, (size_t)nq * sizeof(unsigned int), s));
+    }
     MergeArgs m = {};
     m.keys = a.part;
     m.per_query = (long long)a.S * k;
@@ -758,10 +792,10 @@ int gemm_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float
         // bf16 pass over bf16 copies, fp32 re-scoring of the kept rows, and -- only if a buffer
         // overflowed -- the fp32 kernel below, which then redoes the whole batch
         if (int rc = prefilter_sync_rows(h, s)) return rc;
-        __bf16* qb = reinterpret_cast<__bf16*>(w + p.cand_bytes + p.part_bytes);
-        float* margin = reinterpret_cast<float*>(w + p.cand_bytes + p.part_bytes + p.qb_bytes);
-        u64* part16 = reinterpret_cast<u64*>(w + p.cand_bytes + p.part_bytes + p.qb_bytes + p.margin_bytes);
-        int* flag = reinterpret_cast<int*>(w + p.cand_bytes + p.part_bytes + p.qb_bytes + p.margin_bytes + p.part16_bytes);
+        __bf16* qb = reinterpret_cast<__bf16*>(w + p.cand_bytes + p.part_bytes + p.gthr_bytes);
+        float* margin = reinterpret_cast<float*>(w + p.cand_bytes + p.part_bytes + p.gthr_bytes + p.qb_bytes);
+        u64* part16 = reinterpret_cast<u64*>(w + p.cand_bytes + p.part_bytes + p.gthr_bytes + p.qb_bytes + p.margin_bytes);
+        int* flag = reinterpret_cast<int*>(w + p.cand_bytes + p.part_bytes + p.gthr_bytes + p.qb_bytes + p.margin_bytes + p.part16_bytes);
         RAG_HIP_CHECK(hipMemsetAsync(flag, 0, 256, s));
         hipLaunchKernelGGL(queries_to_bf16_kernel, dim3((unsigned)nq), dim3(64), 0, s, qbuf, h->ld, h->xb_maxnorm, qb, margin);
         RAG_HIP_CHECK(hipGetLastError());
