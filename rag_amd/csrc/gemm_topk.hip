@@ -76,8 +76,11 @@ constexpr int GEMM_MAX_K = 64;
 // more than TRIG keys at the end of a tile; a tile adds at most RT, so it holds TRIG + RT.
 // Narrow shapes see few rows per workgroup (the corpus is split 512 ways for a single query
 // block), so they tighten early and often; the square shape streams long ranges and rarely compacts.
-__host__ __device__ constexpr int gemm_trig(int RT, int QT) { return QT >= 128 ? RT : 64; }
-__host__ __device__ constexpr int gemm_capq(int RT, int QT) { return gemm_trig(RT, QT) + RT; }
+// The narrow shapes trigger at 64 keys for k <= 32 and at 128 above (a trigger below 2k would
+// compact after every tile); their buffers are sized for the larger one.
+__host__ __device__ constexpr int gemm_trig_max(int RT, int QT) { return QT >= 128 ? RT : 128; }
+__host__ __device__ constexpr int gemm_trig(int RT, int QT, int k) { return QT >= 128 ? RT : (k <= 32 ? 64 : 128); }
+__host__ __device__ constexpr int gemm_capq(int RT, int QT) { return gemm_trig_max(RT, QT) + RT; }
 
 // Timing-only ablations for diagnostic builds (outputs are wrong when non-zero):
 // bit 0 skip the tile epilogue, bit 1 load global tiles only once, bit 2 barrier only twice,
@@ -136,7 +139,7 @@ __device__ __forceinline__ void push_candidate(const GemmArgs& a, u64* cand, int
     if (row < row_hi && (!a.mask || a.mask[row])) {
         const int pos = atomicAdd(&s_cnt[ql], 1);
         cand[(size_t)ql * CAPQ + pos] = make_key(sc, (uint32_t)(a.row_alias ? a.row_alias[row] : row));
-        if (pos + 1 > gemm_trig(RT, QT)) *s_flag = 1;       // compact before the next tile can overflow it
+        if (pos + 1 > gemm_trig(RT, QT, a.k)) *s_flag = 1;       // compact before the next tile can overflow it
     }
 }
 
@@ -160,7 +163,7 @@ template <int RT, int QT, int NW, bool B16>
 __device__ __forceinline__ void compact_queries(u64* scratch, u64* cand, int* s_cnt, float* s_thr, const float* s_margin,
                                                 int* overflow, unsigned int* gthr, int k, int wave, int lane) {
     constexpr int CAPQ = gemm_capq(RT, QT);
-    constexpr int TRIG = gemm_trig(RT, QT);
+    const int TRIG = gemm_trig(RT, QT, k);
     for (int ql = wave; ql < QT; ql += NW) {
         const int c = s_cnt[ql];
         if (c <= TRIG) continue;            // wave-uniform
