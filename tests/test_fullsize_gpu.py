@@ -93,3 +93,49 @@ def test_halves_merge_to_whole(corpus):
     both_I = np.concatenate([Is[:, 0], Is[:, 1]], axis=1)
     order = np.lexsort((both_I, -both_D), axis=1)[:, :K]
     assert np.array_equal(np.take_along_axis(both_I, order, 1), Iw.cpu().numpy())
+
+
+def test_every_gemm_shape_agrees_with_the_scan(corpus):
+    """The four tile shapes (12, 64, 200 and 1100 queries) against single-query scans of the same
+    index: identical ids, scores within tolerance."""
+    torch, X, Q, idx, planted = corpus
+    from bench import make_queries
+    Qbig = make_queries(torch, 1100, D, X.device)            # the first 64 equal Q (same seed)
+    assert torch.equal(Qbig[:64], Q)
+    scans = {}
+    for qi in (0, 5, 11, 40, 63, 150, 199, 700, 1099):
+        Ds, Is = idx.search(Qbig[qi:qi + 1], K)
+        assert idx.last_path == "scan"
+        scans[qi] = (Ds.cpu().numpy()[0], Is.cpu().numpy()[0])
+    for nq in (12, 64, 200, 1100):
+        Dg, Ig = idx.search(Qbig[:nq], K)
+        assert idx.last_path == "gemm"
+        Dg, Ig = Dg.cpu().numpy(), Ig.cpu().numpy()
+        for qi, (Ds, Is) in scans.items():
+            if qi < nq:
+                assert np.array_equal(Ig[qi], Is), (nq, qi)
+                assert np.allclose(Dg[qi], Ds, rtol=1e-5, atol=1e-6)
+
+
+def test_bf16_first_pass_returns_the_fp32_answer(corpus):
+    """Opt-in bf16 first pass at full size: one query (scan of the bf16 rows) and 1100 queries
+    (bf16 MFMA pass) give the ids of the fp32 paths."""
+    torch, X, Q, idx, planted = corpus
+    from bench import make_queries
+    Qbig = make_queries(torch, 1100, D, X.device)
+    D32, I32 = idx.search(Qbig, K)
+    assert idx.last_path == "gemm"
+    singles = {qi: idx.search(Qbig[qi:qi + 1], K) for qi in (0, 3, 64, 500, 1099)}
+    idx.set_prefilter(True)
+    try:
+        D16, I16 = idx.search(Qbig, K)
+        assert idx.last_path == "gemm-bf16"
+        assert torch.equal(I16, I32)
+        assert np.allclose(D16.cpu().numpy(), D32.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        for qi, (Ds, Is) in singles.items():
+            Dp, Ip = idx.search(Qbig[qi:qi + 1], K)
+            assert idx.last_path == "scan-bf16"
+            assert torch.equal(Ip, Is)
+            assert np.allclose(Dp.cpu().numpy(), Ds.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    finally:
+        idx.set_prefilter(False)
