@@ -76,7 +76,7 @@ int rag_index_set_id_base(rag_index_t* h, int64_t base);
  * from 512 queries, dim % 64 == 0, FLAT): mode 1 keeps a bf16 copy of the rows, runs the
  * contraction on bf16 matrix cores and keeps every row whose approximate score is within a
  * proven error margin of the k-th best; those rows are re-scored in fp32 and the k best are
- * returned, so ids and scores are those of the fp32 path.  A single query with k <= 16 scans the
+ * returned, so ids and scores are those of the fp32 path.  A single query with k <= 256 scans the
  * bf16 rows instead of the fp32 ones under the same guarantee (half the bytes).  Costs dim*2 bytes per row of device
  * memory.  mode 0 (default) switches it off and frees the copy. */
 int rag_index_set_prefilter(rag_index_t* h, int mode);

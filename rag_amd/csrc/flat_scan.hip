@@ -74,13 +74,13 @@ __device__ __forceinline__ f4 load_row4(const f4* p) {
 }
 
 // B16  rows are bf16 (d4 counts their 16-byte chunks, 8 elements each), the query stays fp32;
-//      one query, register list, compile-time chunk count only
+//      one query, compile-time chunk count only
 template <int LPR, int CH, int U, int NQ, bool BIGK, bool NT, bool B16 = false>
 __global__ __launch_bounds__(256) void flat_scan_kernel(ScanArgs a) {
     constexpr int RPS = 64 / LPR;
     constexpr int TILE = RPS * U;
     static_assert(!BIGK || NQ == 1, "LDS-buffer selection handles one query per launch");
-    static_assert(!B16 || (NQ == 1 && !BIGK && CH > 0), "bf16 rows: one query, k <= 64, compile-time width");
+    static_assert(!B16 || (NQ == 1 && CH > 0), "bf16 rows: one query, compile-time width");
     if (a.run_if && *a.run_if == 0) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -550,9 +550,9 @@ static hipError_t launch_scan_t2(const ScanArgs& a, int blocks, size_t lds, hipS
 
 template <int LPR, int CH, int U, int NQ, bool BIGK>
 static hipError_t launch_scan_t(const ScanArgs& a, int blocks, size_t lds, hipStream_t s) {
-    if constexpr (NQ == 1 && !BIGK && CH > 0) {
-        if (a.b16) return a.nt ? launch_scan_t2<LPR, CH, U, 1, false, true, true>(a, blocks, lds, s)
-                               : launch_scan_t2<LPR, CH, U, 1, false, false, true>(a, blocks, lds, s);
+    if constexpr (NQ == 1 && CH > 0) {
+        if (a.b16) return a.nt ? launch_scan_t2<LPR, CH, U, 1, BIGK, true, true>(a, blocks, lds, s)
+                               : launch_scan_t2<LPR, CH, U, 1, BIGK, false, true>(a, blocks, lds, s);
     }
     if (a.b16) return hipErrorInvalidValue;
     return a.nt ? launch_scan_t2<LPR, CH, U, NQ, BIGK, true>(a, blocks, lds, s)

@@ -1001,14 +1001,18 @@ int ivf_listmajor_scan(rag_index* h, long long nq, const float* qbuf, int k, flo
 // score + delta), delta >= |approximate - exact| for every row: then no row outside the kept set
 // can reach the top k.  Otherwise it raises the flag and the fp32 scan enqueued behind it
 // (run_if = flag) answers.  The query stays fp32, so delta = PREF_ERR1 * max row norm * |q|.
-constexpr int PRE1 = 64;
+constexpr int PRE1_MAX = 1024;
+// rows kept by the approximate scan for a request of k: 64 (register lists) up to k = 16, 1024
+// (LDS lists) up to k = 256
+static int pre1_for(int k) { return k <= 16 ? 64 : 1024; }
 constexpr float PREF_ERR1 = 0.0021f;     // 2^-9 (rows rounded to bf16) + accumulation slack
 
 int scan_blocks(const rag_index* h);     // api.hip
 
 struct VerifyArgs {
-    const float* Dk;        // [PRE1] approximate scores, descending, -FLT_MAX padded
-    const long long* Ik;    // [PRE1] row positions, -1 padded
+    const float* Dk;        // [npre] approximate scores, descending, -FLT_MAX padded
+    const long long* Ik;    // [npre] row positions, -1 padded
+    int npre;               // 64 or 1024 (a power of two)
     const float* X;
     const float* q;         // fp32 padded query
     const int* maxnorm_bits;
@@ -1017,10 +1021,11 @@ struct VerifyArgs {
     MergeArgs fin;
 };
 
-__global__ __launch_bounds__(256) void verify_rescore_kernel(VerifyArgs v) {
-    __shared__ u64 keys[PRE1];
+__global__ __launch_bounds__(1024) void verify_rescore_kernel(VerifyArgs v) {
+    __shared__ u64 keys[PRE1_MAX];
     __shared__ float s_qn;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int PRE1 = v.npre, nwaves = blockDim.x >> 6;
     const int k = v.fin.k;
     const f4* q4 = reinterpret_cast<const f4*>(v.q);
     const int ld4 = v.ld / 4;
@@ -1036,7 +1041,7 @@ __global__ __launch_bounds__(256) void verify_rescore_kernel(VerifyArgs v) {
         ss = wave_sum_to_lane63(ss);
         if (lane == 63) s_qn = sqrtf(ss);
     }
-    for (int i = wave; i < PRE1; i += 4) {
+    for (int i = wave; i < PRE1; i += nwaves) {
         const long long row = v.Ik[i];
         u64 key = KEY_EMPTY;
         if (row >= 0) {
@@ -1055,7 +1060,7 @@ __global__ __launch_bounds__(256) void verify_rescore_kernel(VerifyArgs v) {
         if (lane == 0) keys[i] = key;
     }
     __syncthreads();
-    bitonic_sort_desc_lds(keys, PRE1, tid, 256, SyncBlock());
+    bitonic_sort_desc_lds(keys, PRE1, tid, blockDim.x, SyncBlock());
     // the kept set is everything when the list is not full; else rows outside score at most Dk[PRE1-1] + delta
     const bool full = v.Ik[PRE1 - 1] >= 0;
     const float delta = PREF_ERR1 * __int_as_float(*v.maxnorm_bits) * s_qn * 1.0001f + 1e-30f;
@@ -1063,7 +1068,7 @@ __global__ __launch_bounds__(256) void verify_rescore_kernel(VerifyArgs v) {
     const bool ok = !full || (enough && key_score(keys[k - 1]) > v.Dk[PRE1 - 1] + delta);
     if (tid == 0) *v.flag = ok ? 0 : 1;
     if (ok)
-        for (int j = tid; j < k; j += 256) finalise_scored(v.fin, 0, j, keys[j]);
+        for (int j = tid; j < k; j += blockDim.x) finalise_scored(v.fin, 0, j, keys[j]);
 }
 
 static bool b16_scan_width(int ld) {
@@ -1073,13 +1078,13 @@ static bool b16_scan_width(int ld) {
 }
 
 bool prefilter_scan_supported(const rag_index* h, long long nq, int k) {
-    return h->prefilter && h->kind == RAG_KIND_FLAT && nq == 1 && k <= 16 && b16_scan_width(h->ld) && h->n >= 4096;
+    return h->prefilter && h->kind == RAG_KIND_FLAT && nq == 1 && k <= 256 && b16_scan_width(h->ld) && h->n >= 65536;
 }
 
 // after the padded query: [fp32 scan partial lists | bf16 scan partial lists | PRE1 scores | PRE1 rows | flag]
 size_t prefilter_scan_workspace(const rag_index* h, int k) {
     const size_t blocks = (size_t)scan_blocks(h);
-    return blocks * k * sizeof(u64) + 256 + blocks * PRE1 * sizeof(u64) + 256 + 512 + 512 + 256;
+    return 4 * blocks * k * sizeof(u64) + 256 + 4 * blocks * PRE1_MAX * sizeof(u64) + 256 + PRE1_MAX * 4 + PRE1_MAX * 8 + 256;
 }
 
 int prefilter_scan_search(rag_index* h, const float* qbuf, int k, float min_score, const uint8_t* mask,
@@ -1090,13 +1095,14 @@ int prefilter_scan_search(rag_index* h, const float* qbuf, int k, float min_scor
     if (h->ws.bytes < qbytes + prefilter_scan_workspace(h, k))
         return fail(RAG_ERR_INVALID, "internal: workspace not sized for the bf16 scan");
     char* w = static_cast<char*>(h->ws.ptr) + qbytes;
+    const int PRE1 = pre1_for(k);
     u64* part32 = reinterpret_cast<u64*>(w);
-    w += (((size_t)blocks * k * sizeof(u64)) + 255) & ~(size_t)255;
+    w += (((size_t)4 * blocks * k * sizeof(u64)) + 255) & ~(size_t)255;
     u64* part16 = reinterpret_cast<u64*>(w);
-    w += (((size_t)blocks * PRE1 * sizeof(u64)) + 255) & ~(size_t)255;
+    w += (((size_t)4 * blocks * PRE1_MAX * sizeof(u64)) + 255) & ~(size_t)255;
     float* Dk = reinterpret_cast<float*>(w);
-    long long* Ik = reinterpret_cast<long long*>(w + 512);
-    int* flag = reinterpret_cast<int*>(w + 1024);
+    long long* Ik = reinterpret_cast<long long*>(w + PRE1_MAX * 4);
+    int* flag = reinterpret_cast<int*>(w + PRE1_MAX * 4 + PRE1_MAX * 8);
 
     // 1. approximate scan over the bf16 rows, PRE1 best (score, row position)
     ScanArgs a = {};
@@ -1117,7 +1123,7 @@ int prefilter_scan_search(rag_index* h, const float* qbuf, int k, float min_scor
     if (int rc = profile_end(h, s)) return rc;
     MergeArgs m = {};
     m.keys = part16;
-    m.per_query = (long long)blocks * PRE1;
+    m.per_query = (long long)blocks * scan_lists_per_block(PRE1) * PRE1;
     m.k = PRE1;
     m.cap = merge_cap(m.per_query, PRE1);
     m.min_score = -FLT_MAX;
@@ -1141,7 +1147,8 @@ int prefilter_scan_search(rag_index* h, const float* qbuf, int k, float min_scor
     v.ld = h->ld;
     v.flag = flag;
     v.fin = fin;
-    hipLaunchKernelGGL(verify_rescore_kernel, dim3(1), dim3(256), 0, s, v);
+    v.npre = PRE1;
+    hipLaunchKernelGGL(verify_rescore_kernel, dim3(1), dim3(PRE1 == 64 ? 256 : 1024), 0, s, v);
     RAG_HIP_CHECK(hipGetLastError());
     // 3. the fp32 scan, which runs only if the test failed
     ScanArgs f = {};

@@ -30,7 +30,7 @@ struct ScanArgs {
     int ivf_nprobe;
     int ivf_slices;
     int grid_y;
-    int b16;                      // rows are bf16: d4 = 16-byte chunks of a bf16 row, Q stays fp32 (one query, k <= 64)
+    int b16;                      // rows are bf16: d4 = 16-byte chunks of a bf16 row, Q stays fp32 (one query)
     const int* run_if;            // when not NULL the kernel runs only if *run_if != 0
     int nq_valid;                 // query slots of a pass that hold real queries (0 = all); the rest repeat the last one
 };

@@ -22,6 +22,8 @@ X = make_corpus(torch, 0, rows, dim, dev)
 Q = make_queries(torch, 32, dim, dev).cpu().numpy()
 idx = DeviceIndex(dim, metric="ip")
 idx.adopt(X)
+if os.environ.get("PREFILTER", "0") == "1":
+    idx.set_prefilter(True)
 rng = np.random.default_rng(5)
 stages = {"search_top200_ms": [], "hybrid_fuse_ms": [], "mmr_200_to_10_ms": [], "total_ms": []}
 idx.profile(True)

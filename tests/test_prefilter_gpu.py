@@ -71,7 +71,7 @@ def test_prefilter_falls_back_when_near_ties_overflow():
     idx.close()
 
 
-@pytest.mark.parametrize("n,d", [(200_000, 768), (150_000, 1024), (100_000, 256), (60_000, 1536)])
+@pytest.mark.parametrize("n,d", [(200_000, 768), (150_000, 1024), (100_000, 256), (80_000, 1536)])
 def test_single_query_bf16_scan_matches_oracle(n, d):
     """One query: scan of the bf16 rows, fp32 re-score of the 64 kept rows, acceptance test;
     near-duplicate clusters make some queries fail the test and take the fp32 scan instead."""
@@ -95,9 +95,14 @@ def test_single_query_bf16_scan_matches_oracle(n, d):
             _check(D, I, X, Q[qi:qi + 1], k)
         D, I = idx.search(Q[qi], 10, row_mask=mask, min_score=0.05)
         _check(D, I, X, Q[qi:qi + 1], 10, row_mask=mask, min_score=0.05)
-    D, I = idx.search(Q[2], 17)                       # k above the supported range: plain fp32 scan
+    for k in (17, 100, 200):                          # 1024 rows kept (LDS lists) up to k = 256
+        for qi in (0, 1, 2):
+            D, I = idx.search(Q[qi], k)
+            assert idx.last_path == "scan-bf16"
+            _check(D, I, X, Q[qi:qi + 1], k)
+    D, I = idx.search(Q[2], 300)                      # k above the supported range: plain fp32 scan
     assert idx.last_path == "scan"
-    _check(D, I, X, Q[2:3], 17)
+    _check(D, I, X, Q[2:3], 300)
     idx.close()
 
 
@@ -106,7 +111,7 @@ def test_quantization_config_switches_the_first_pass_on():
     from rag_amd.schemas import MetricType, SearchConfig
     from rag_amd.search_optimizer import HipSearchOptimizer
     rng = np.random.default_rng(3)
-    n, d = 20_000, 256
+    n, d = 70_000, 256
     X = _unit(rng, n, d)
     opt = HipSearchOptimizer(SearchConfig(dimension=d, metric=MetricType.COSINE, collection_name="c",
                                           quantization_config={"scalar": {"type": "int8"}}))
