@@ -78,7 +78,8 @@ int rag_index_set_id_base(rag_index_t* h, int64_t base);
  * proven error margin of the k-th best; those rows are re-scored in fp32 and the k best are
  * returned, so ids and scores are those of the fp32 path.  A single query with k <= 256 scans the
  * bf16 rows instead of the fp32 ones under the same guarantee (half the bytes).  Costs dim*2 bytes per row of device
- * memory.  mode 0 (default) switches it off and frees the copy. */
+ * memory.  mode 0 (default) switches it off and frees the copy.  The copy follows rows that are
+ * added; a caller who rewrites rows of an adopted buffer in place switches the mode off and on. */
 int rag_index_set_prefilter(rag_index_t* h, int mode);
 int64_t rag_index_ntotal(const rag_index_t* h);
 int rag_index_dim(const rag_index_t* h);
