@@ -143,7 +143,9 @@ __device__ __forceinline__ void push_candidate(const GemmArgs& a, u64* cand, int
     }
 }
 
-constexpr int PREF_OUTC = 128;   // bf16 pass: keys a (query, row range) may hand to the re-scoring step
+// bf16 pass: keys a (query, row range) may hand to the re-scoring step -- 128, or 64 when one query
+// block is split over more than 128 row ranges (each range then sees few rows and keeps few)
+static int pref_outc(int S) { return S <= 128 ? 128 : 64; }
 
 // number of leading keys of a descending list whose score is above `thr` (wave-wide, n <= 512)
 __device__ __forceinline__ int count_above(const u64* sorted, int n, float thr, int lane) {
@@ -500,11 +502,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
             if constexpr (B16) {
                 int keep = c;
                 if (c >= k) keep = count_above(scratch, c, key_score(scratch[k - 1]) - s_margin[ql], lane);
-                if (keep > PREF_OUTC) {
+                if (keep > a.outc) {
                     if (lane == 0) *a.overflow = 1;
-                    keep = PREF_OUTC;
+                    keep = a.outc;
                 }
-                for (int i = lane; i < PREF_OUTC; i += 64) out[i] = i < keep ? scratch[i] : KEY_EMPTY;
+                for (int i = lane; i < a.outc; i += 64) out[i] = i < keep ? scratch[i] : KEY_EMPTY;
             } else {
                 for (int i = lane; i < k; i += 64) out[i] = scratch[i];
             }
@@ -520,8 +522,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
 // find the k-th best approximate score, re-score in fp32 every row within the margin of it,
 // select the k best exact scores.
 struct RescoreArgs {
-    const u64* part;        // [nq][S * PREF_OUTC]
-    int per_query;          // S * PREF_OUTC
+    const u64* part;        // [nq][S * outc]
+    int per_query;          // S * outc
     const float* X;         // fp32 rows
     const float* Q;         // fp32 padded queries
     const float* margin;
@@ -529,7 +531,7 @@ struct RescoreArgs {
     int* overflow;
     MergeArgs fin;          // k, min_score, id mapping, D, I
 };
-constexpr int RESC_CAP = 4096;      // keys of one query that fit the selection buffer
+constexpr int RESC_CAP = 8192;      // keys of one query that fit the selection buffer (64 KB of LDS)
 
 __device__ __forceinline__ void finalise_scored(const MergeArgs& a, long long q, int j, u64 key) {
     float s = -3.402823466e+38f;
@@ -547,8 +549,9 @@ __device__ __forceinline__ void finalise_scored(const MergeArgs& a, long long q,
 }
 
 __global__ __launch_bounds__(256) void rescore_select_kernel(RescoreArgs r) {
-    __shared__ u64 buf[RESC_CAP];
-    __shared__ int s_n;
+    extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
+    u64* buf = reinterpret_cast<u64*>(rs_smem);                        // [RESC_CAP]
+    int& s_n = *reinterpret_cast<int*>(buf + RESC_CAP);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long q = blockIdx.x;
     const int k = r.fin.k;
@@ -672,9 +675,9 @@ static GemmPlan gemm_plan(const rag_index* h, long long nq, int k) {
     static const int force_qt = env_int_g("RAG_GEMM_QT", 0);
     static const int big_min_nq = env_int_g("RAG_GEMM_BIG_MIN_NQ", 1024);
     GemmPlan p;
-    // with the bf16 first pass on, the 256 x 256 shape (the one it runs in) already pays from 512 queries
-    const int big_from = h->prefilter ? std::min(big_min_nq, 512) : big_min_nq;
-    p.QT = force_qt ? force_qt : (nq <= 32 ? 32 : nq <= 64 ? 64 : nq < big_from ? 128 : 256);
+    // with the bf16 first pass on, the 256 x 256 shape (the one it runs in) already pays from 33 queries
+    const int big_from = h->prefilter ? std::min(big_min_nq, 33) : big_min_nq;
+    p.QT = force_qt ? force_qt : (nq >= big_from ? 256 : nq <= 32 ? 32 : nq <= 64 ? 64 : 128);
     p.RT = (p.QT == 32 || p.QT == 256) ? 256 : 128;
     p.NW = p.QT == 256 ? 8 : 4;
     const int target_wgs = target_wgs_env > 0 ? target_wgs_env : (p.NW == 8 ? 256 : 512);
@@ -699,10 +702,10 @@ static GemmPlan gemm_plan(const rag_index* h, long long nq, int k) {
     p.part_bytes = ((size_t)nq * p.S * k * sizeof(u64) + 255) & ~(size_t)255;
     p.gthr_bytes = ((size_t)nq * sizeof(unsigned int) + 255) & ~(size_t)255;
     // the bf16 first pass pays off where the batch is MFMA-bound: the 256 x 256 shape
-    p.pref = h->prefilter && p.QT == 256 && (h->ld % (2 * GK)) == 0 && (long long)p.S * PREF_OUTC <= 16384;
+    p.pref = h->prefilter && p.QT == 256 && (h->ld % (2 * GK)) == 0 && (long long)p.S * pref_outc(p.S) <= 16384;
     p.qb_bytes = p.pref ? (((size_t)nq * h->ld * 2 + 255) & ~(size_t)255) : 0;
     p.margin_bytes = p.pref ? (((size_t)nq * sizeof(float) + 255) & ~(size_t)255) : 0;
-    p.part16_bytes = p.pref ? (size_t)nq * p.S * PREF_OUTC * sizeof(u64) : 0;
+    p.part16_bytes = p.pref ? (size_t)nq * p.S * pref_outc(p.S) * sizeof(u64) : 0;
     return p;
 }
 
@@ -808,20 +811,29 @@ int gemm_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float
         b.part = part16;
         b.margin = margin;
         b.overflow = flag;
-        b.outc = PREF_OUTC;
+        b.outc = pref_outc(p.S);
         if (int rc = profile_begin(h, s)) return rc;
         if (int rc = launch_gemm<256, 256, 8, true>(b, grid, h->device, s)) return rc;
         if (int rc = profile_end(h, s)) return rc;
         RescoreArgs r = {};
         r.part = part16;
-        r.per_query = p.S * PREF_OUTC;
+        r.per_query = p.S * pref_outc(p.S);
         r.X = h->X;
         r.Q = qbuf;
         r.margin = margin;
         r.ld = h->ld;
         r.overflow = flag;
         r.fin = m;
-        hipLaunchKernelGGL(rescore_select_kernel, dim3((unsigned)nq), dim3(256), 0, s, r);
+        {
+            constexpr size_t rlds = (size_t)RESC_CAP * sizeof(u64) + 16;
+            static bool rattr[64] = {};
+            if (!rattr[h->device & 63]) {
+                RAG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(rescore_select_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
+                rattr[h->device & 63] = true;
+            }
+            hipLaunchKernelGGL(rescore_select_kernel, dim3((unsigned)nq), dim3(256), rlds, s, r);
+        }
         RAG_HIP_CHECK(hipGetLastError());
         a.run_if = flag;
         m.run_if = flag;

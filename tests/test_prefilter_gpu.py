@@ -24,7 +24,7 @@ def _check(D, I, X, Q, k, **kw):
 
 
 @pytest.mark.parametrize("n,d,nq,k", [(60_000, 768, 1024, 10), (30_000, 384, 1500, 64), (20_000, 1024, 2048, 1),
-                                      (700, 128, 1100, 10), (50_000, 768, 600, 10)])
+                                      (700, 128, 1100, 10), (50_000, 768, 600, 10), (90_000, 768, 130, 10), (120_000, 384, 300, 16), (70_000, 768, 40, 10)])
 def test_prefilter_matches_oracle(n, d, nq, k):
     from rag_amd import DeviceIndex
     rng = np.random.default_rng(n + d + nq)
