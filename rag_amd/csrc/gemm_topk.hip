@@ -676,7 +676,8 @@ static GemmPlan gemm_plan(const rag_index* h, long long nq, int k) {
     static const int big_min_nq = env_int_g("RAG_GEMM_BIG_MIN_NQ", 1024);
     GemmPlan p;
     // with the bf16 first pass on, the 256 x 256 shape (the one it runs in) already pays from 33 queries
-    const int big_from = h->prefilter ? std::min(big_min_nq, 33) : big_min_nq;
+    // (on a corpus long enough to give a single query block its 128+ row ranges)
+    const int big_from = (h->prefilter && h->n >= 262144) ? std::min(big_min_nq, 33) : big_min_nq;
     p.QT = force_qt ? force_qt : (nq >= big_from ? 256 : nq <= 32 ? 32 : nq <= 64 ? 64 : 128);
     p.RT = (p.QT == 32 || p.QT == 256) ? 256 : 128;
     p.NW = p.QT == 256 ? 8 : 4;

@@ -24,7 +24,7 @@ def _check(D, I, X, Q, k, **kw):
 
 
 @pytest.mark.parametrize("n,d,nq,k", [(60_000, 768, 1024, 10), (30_000, 384, 1500, 64), (20_000, 1024, 2048, 1),
-                                      (700, 128, 1100, 10), (50_000, 768, 600, 10), (90_000, 768, 130, 10), (120_000, 384, 300, 16), (70_000, 768, 40, 10)])
+                                      (700, 128, 1100, 10), (50_000, 768, 600, 10), (540_000, 384, 130, 10), (600_000, 256, 300, 16), (524_288, 128, 40, 10)])
 def test_prefilter_matches_oracle(n, d, nq, k):
     from rag_amd import DeviceIndex
     rng = np.random.default_rng(n + d + nq)
@@ -33,12 +33,14 @@ def test_prefilter_matches_oracle(n, d, nq, k):
     idx = DeviceIndex(d, metric="ip")
     idx.add(X[: n // 2])
     idx.set_prefilter(True)
+    def path(rows):          # the bf16 pass starts at 1024 queries, at 33 on a corpus of 262144+ rows
+        return "gemm-bf16" if nq >= 1024 or (rows >= 262144 and nq >= 33) else "gemm"
     D, I = idx.search(Q, k)
-    assert idx.last_path == "gemm-bf16"
+    assert idx.last_path == path(n // 2)
     _check(D, I, X[: n // 2], Q, k)
     idx.add(X[n // 2:])                          # rows appended after the bf16 copy was made
     D, I = idx.search(Q, k)
-    assert idx.last_path == "gemm-bf16"
+    assert idx.last_path == path(n)
     _check(D, I, X, Q, k)
     mask = (rng.uniform(size=n) < 0.3).astype(np.uint8)
     D, I = idx.search(Q, k, row_mask=mask, min_score=0.02)
