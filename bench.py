@@ -11,7 +11,10 @@ queries already resident in HBM: query preparation, corpus scan, selection,
 merge and, for N > 1, the all-gather of per-shard candidates plus the device
 merge.  N > 1 shards the SAME corpus row-wise over the ranks (strong scaling:
 total work per step is fixed).  Rank 0 prints one JSON line; `value` is the
-batch-1 rate, the batch-4096 rate is reported beside it.
+batch-1 fp32 rate.  Beside it: `batch_4096` and `batch_32` (fp32 MFMA path), and --
+clearly labelled, never `value` -- `batch_4096_bf16_first_pass` / `batch_1_bf16_first_pass`,
+the opt-in mode that searches a bf16 copy first and re-scores the kept rows in fp32
+(same answers).
 """
 from __future__ import annotations
 
