@@ -1,0 +1,45 @@
+"""Randomised shapes against the oracle: corpus size, width, batch size, k, masks and the bf16
+first pass are drawn from a fixed seed, so every kernel shape and its edges (partial tiles, partial
+query blocks, few rows per range) get exercised together."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-5, 1e-6
+
+
+def _unit(rng, n, d):
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return x
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_configurations(seed):
+    from oracle import flat
+    from rag_amd import DeviceIndex
+    rng = np.random.default_rng(1000 + seed)
+    for _ in range(7):
+        d = int(rng.choice([32, 64, 96, 128, 256, 384, 512, 768, 1024, 100, 36]))
+        n = int(rng.integers(1, 60_000)) if rng.uniform() < 0.8 else int(rng.integers(262_144, 300_000))
+        if n > 100_000:
+            d = int(rng.choice([64, 128]))
+        nq = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 300, 1030]))
+        k = int(rng.choice([1, 2, 5, 10, 16, 17, 32, 33, 64, 65, 100]))
+        X = _unit(rng, n, d) * rng.uniform(0.5, 1.5, (n, 1)).astype(np.float32)
+        if n > 50 and rng.uniform() < 0.3:
+            X[n // 3: n // 3 + 20] = X[0]                      # exact ties
+        Q = _unit(rng, nq, d)
+        mask = (rng.uniform(size=n) < 0.6).astype(np.uint8) if rng.uniform() < 0.4 else None
+        min_score = float(rng.choice([-1e30, 0.0, 0.05]))
+        idx = DeviceIndex(d, metric="ip")
+        idx.add(X)
+        if rng.uniform() < 0.4:
+            idx.set_prefilter(True)
+        D, I = idx.search(Q, k, row_mask=mask, min_score=min_score)
+        Dr, Ir = flat.flat_ip_search(X, Q, k, row_mask=mask, min_score=min_score)
+        bad = flat.compare_topk(D, I, Dr, Ir, rtol=RTOL, atol=ATOL)
+        assert bad == [], (dict(n=n, d=d, nq=nq, k=k, path=idx.last_path, mask=mask is not None,
+                                min_score=min_score), bad[:3])
+        idx.close()
