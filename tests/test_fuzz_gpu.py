@@ -43,3 +43,32 @@ def test_random_configurations(seed):
         assert bad == [], (dict(n=n, d=d, nq=nq, k=k, path=idx.last_path, mask=mask is not None,
                                 min_score=min_score), bad[:3])
         idx.close()
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_random_ivf_configurations(seed):
+    from oracle import flat, ivf
+    from rag_amd import DeviceIndex
+    rng = np.random.default_rng(2000 + seed)
+    for _ in range(4):
+        d = int(rng.choice([32, 64, 128, 256, 100]))
+        n = int(rng.integers(2_000, 50_000))
+        nlist = int(rng.choice([4, 16, 50, 128]))
+        nprobe = int(rng.integers(1, min(nlist, 24) + 1))
+        nq = int(rng.choice([1, 3, 7, 40, 200, 700]))
+        k = int(rng.choice([1, 10, 33, 64, 100]))
+        X = _unit(rng, n, d)
+        C = _unit(rng, nlist, d)
+        Q = _unit(rng, nq, d)
+        mask = (rng.uniform(size=n) < 0.7).astype(np.uint8) if rng.uniform() < 0.4 else None
+        idx = DeviceIndex(d, metric="ip", kind="ivf")
+        idx.train_ivf(nlist, centroids=C)
+        cut = int(rng.integers(1, n))
+        idx.add(X[:cut])
+        idx.search(Q[:1], 1, nprobe=nprobe)                    # packs the first part
+        idx.add(X[cut:])
+        D, I = idx.search(Q, k, nprobe=nprobe, row_mask=mask)
+        Dr, Ir = ivf.ivf_search(X, C, Q, k, nprobe, row_mask=mask)
+        bad = flat.compare_topk(D, I, Dr, Ir, rtol=RTOL, atol=ATOL)
+        assert bad == [], (dict(n=n, d=d, nlist=nlist, nprobe=nprobe, nq=nq, k=k, path=idx.last_path), bad[:3])
+        idx.close()
