@@ -126,6 +126,9 @@ struct GemmArgs {
 };
 
 // cache policy bits of the corpus loads in the narrow shapes (2 = non-temporal)
+#ifndef RAG_B16_SCHED
+#define RAG_B16_SCHED 1
+#endif
 #ifndef RAG_GEMM_NARROW_AUX
 #define RAG_GEMM_NARROW_AUX 2
 #endif
@@ -432,7 +435,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
             for (int mi = 0; mi < 2; ++mi) fa[0][mi] = *reinterpret_cast<const f4*>(Ab + mi * 32 * GK + foff[0]);
 #pragma unroll
             for (int nj = 0; nj < NJ; ++nj) fb[0][nj] = *reinterpret_cast<const f4*>(Bb + nj * 32 * GK + foff[0]);
-            if (!B16) __builtin_amdgcn_sched_group_barrier(0x100, READS, 0);
+            if (!B16 || RAG_B16_SCHED) __builtin_amdgcn_sched_group_barrier(0x100, READS, 0);
 #pragma unroll
             for (int kb = 0; kb < GK / 8; ++kb) {
                 const int cur = kb & 1, nxt = cur ^ 1;
@@ -458,6 +461,19 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
 #pragma unroll
                             for (int nj = 0; nj < NJ; ++nj)
                                 acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][mi][s], fb[cur][nj][s], acc[mi][nj], 0, 0, 0);
+                }
+                if constexpr (B16 && RAG_B16_SCHED) {
+                    // 2*NJ MFMAs per block: one read behind each of the first READS MFMAs
+                    if (kb + 1 < GK / 8) {
+#pragma unroll
+                        for (int j = 0; j < READS; ++j) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ - READS, 0);
+                    } else {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2 * NJ, 0);
+                    }
                 }
                 if constexpr (!B16) {
                     if (kb + 1 < GK / 8) {
