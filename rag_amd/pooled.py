@@ -9,14 +9,54 @@ vector type and dimension is a set of row ranges ("segments") of a single
 ``DeviceIndex``, and the whole fan-out is ONE call of ``rag_index_search_segments``:
 the k best of every (query vector, collection) pair.  Results per pair are the
 same as a search of that collection alone.
+
+``PooledView`` gives one collection of a pool the method set of
+``HipSearchOptimizer``, so that it registers in
+``VectorStorageManager.search_optimizers`` like any other backend object.
 """
 from __future__ import annotations
 
+import logging
+import time
 from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
 from .index import DeviceIndex
+from .schemas import Chunk, SearchConfig, SearchError
+
+
+def _match(value, wanted) -> bool:
+    """Qdrant MatchValue: equality, or membership when the payload field is a list."""
+    if isinstance(value, (list, tuple)):
+        return wanted in value
+    return value == wanted
+
+
+def payload_passes(payload: Dict[str, Any], filters: Dict[str, Any]) -> bool:
+    """vector_db/search_optimizer.py:173-201: every condition must hold
+    (Filter(must=...)); a list value adds one equality condition per element;
+    {'range': {...}} is a numeric range; anything else is equality."""
+    for key, value in filters.items():
+        pv = payload.get(key)
+        if isinstance(value, list):
+            if pv is None or not all(_match(pv, v) for v in value):
+                return False
+        elif isinstance(value, dict) and "range" in value:
+            arg = value["range"]
+            if not isinstance(pv, (int, float)) or isinstance(pv, bool):
+                return False
+            if arg.get("gte") is not None and not pv >= arg["gte"]:
+                return False
+            if arg.get("lte") is not None and not pv <= arg["lte"]:
+                return False
+            if arg.get("gt") is not None and not pv > arg["gt"]:
+                return False
+            if arg.get("lt") is not None and not pv < arg["lt"]:
+                return False
+        elif pv is None or not _match(pv, value):
+            return False
+    return True
 
 
 class PooledCollections:
@@ -26,7 +66,10 @@ class PooledCollections:
         self.ranges: Dict[str, List[List[int]]] = {}        # collection -> [[begin, end), ...]
         self.payloads: List[Dict[str, Any]] = []            # row -> payload
         self.point_ids: List[Any] = []                      # row -> point id
-        self._row_of: Dict[Tuple[str, Any], int] = {}       # (collection, point id) -> live row
+        self._rows: Dict[str, Dict[Any, int]] = {}          # collection -> {point id -> live row}
+        self._hidden: set = set()                           # soft-deleted collections
+        self._version = 0                                   # bumped by every change of rows or payloads
+        self._mask_cache: Dict[Tuple[str, str], Tuple[int, np.ndarray]] = {}
 
     def close(self) -> None:
         self.index.close()
@@ -35,7 +78,10 @@ class PooledCollections:
         return list(self.ranges.keys())
 
     def count(self, name: str) -> int:
-        return sum(1 for (c, _i) in self._row_of if c == name)
+        return len(self._rows.get(name, ()))
+
+    def row_of(self, name: str, point_id) -> Optional[int]:
+        return self._rows.get(name, {}).get(point_id)
 
     def upsert(self, name: str, vectors, payloads: Sequence[Dict[str, Any]], ids: Sequence[Any]) -> None:
         x = np.ascontiguousarray(vectors, dtype=np.float32)
@@ -43,11 +89,12 @@ class PooledCollections:
             raise ValueError(f"expected vectors of dimension {self.dimension}")
         if not (len(payloads) == len(ids) == x.shape[0]):
             raise ValueError("vectors, payloads and ids must have the same length")
+        rows = self._rows.setdefault(name, {})
         if x.shape[0] == 0:
             self.ranges.setdefault(name, [])
             return
         first = len(self.payloads)
-        stale = [self._row_of[(name, i)] for i in ids if (name, i) in self._row_of]
+        stale = [rows[i] for i in ids if i in rows]
         self.index.add(x)
         rng = self.ranges.setdefault(name, [])
         if rng and rng[-1][1] == first:
@@ -57,22 +104,52 @@ class PooledCollections:
         for j, (p, i) in enumerate(zip(payloads, ids)):
             self.payloads.append(dict(p) if p else {})
             self.point_ids.append(i)
-            self._row_of[(name, i)] = first + j
+            rows[i] = first + j
         if stale:
             self.index.set_active(stale, False)
+        if name in self._hidden:                            # a hidden collection stays hidden
+            self.index.set_active(list(range(first, first + x.shape[0])), False)
+        self._version += 1
+
+    def set_collection_active(self, name: str, active: bool) -> None:
+        """vector_db/qdrant_client.py:826-883: hide / restore every point of a collection."""
+        rows = sorted(self._rows.get(name, {}).values())
+        if rows:
+            self.index.set_active(rows, active)
+        (self._hidden.discard if active else self._hidden.add)(name)
 
     def drop(self, name: str) -> None:
         """Remove a collection: its rows stay allocated but are never returned."""
-        rows = [r for (c, _i), r in self._row_of.items() if c == name]
+        rows = list(self._rows.get(name, {}).values())
         if rows:
             self.index.set_active(rows, False)
-        for key in [key for key in self._row_of if key[0] == name]:
-            del self._row_of[key]
+        self._rows.pop(name, None)
         self.ranges.pop(name, None)
+        self._hidden.discard(name)
+        self._version += 1
 
     def get_vector(self, name: str, point_id) -> Optional[np.ndarray]:
-        row = self._row_of.get((name, point_id))
+        row = self.row_of(name, point_id)
         return None if row is None else self.index.reconstruct([row])[0]
+
+    def filter_mask(self, names: Sequence[str], filters: Optional[Dict[str, Any]]) -> Optional[np.ndarray]:
+        """One byte per pool row: 1 where the payload passes ``filters``, decided
+        for the rows of ``names`` only (other rows are never scanned by the
+        caller).  The per-collection pieces are kept until the pool changes, so a
+        repeated filter (the per-user filter of vector_db/search_manager.py:893)
+        costs one copy."""
+        if not filters:
+            return None
+        fkey = repr(sorted(filters.items(), key=lambda kv: kv[0]))
+        mask = np.zeros(len(self.payloads), dtype=np.uint8)
+        for name in names:
+            hit = self._mask_cache.get((name, fkey))
+            if hit is None or hit[0] != self._version:
+                rows = np.fromiter((r for r in self._rows.get(name, {}).values()
+                                    if payload_passes(self.payloads[r], filters)), dtype=np.int64)
+                self._mask_cache[(name, fkey)] = hit = (self._version, rows)
+            mask[hit[1]] = 1
+        return mask
 
     def search_many(self, names: Sequence[str], query_vectors, limit: int, min_score: Optional[float] = 0.0,
                     row_mask=None) -> List[List[List[Tuple[int, float]]]]:
@@ -91,15 +168,139 @@ class PooledCollections:
         if not segs or limit < 1:
             return out
         D, I = self.index.search_segments(q, segs, limit, min_score=min_score, row_mask=row_mask)
+        # unfilled slots (-1) sit at the end of every list: one count per list, then plain slices
+        counts = (np.asarray(I) >= 0).sum(axis=-1).tolist()
+        rows, scores = np.asarray(I).tolist(), np.asarray(D).tolist()
+        pieces = [0] * len(names)
+        for ci in owner:
+            pieces[ci] += 1
         for qi in range(q.shape[0]):
-            per = [[] for _ in names]
+            per = out[qi]
+            rq, sq, cq = rows[qi], scores[qi], counts[qi]
             for si, ci in enumerate(owner):
-                for s, r in zip(D[qi, si], I[qi, si]):
-                    if r < 0:
-                        break
-                    per[ci].append((int(r), float(s)))
+                c = cq[si]
+                if c:
+                    per[ci].extend(zip(rq[si][:c], sq[si][:c]))
             for ci, hits in enumerate(per):
-                if sum(1 for c in owner if c == ci) > 1:     # collection spread over several ranges
+                if pieces[ci] > 1:                           # collection spread over several ranges
                     hits.sort(key=lambda t: (-t[1], t[0]))
-                out[qi][ci] = hits[:limit]
+                    del hits[limit:]
         return out
+
+    def chunks_of(self, hits: Sequence[Tuple[int, float]]) -> List[Tuple[Chunk, float]]:
+        """(row, score) pairs as the reference's (Chunk, score) tuples
+        (vector_db/search_optimizer.py:228-258)."""
+        out = []
+        for row, score in hits:
+            payload = self.payloads[row] or {}
+            chunk_id = payload.get("chunk_id") or str(self.point_ids[row])
+            out.append((Chunk(document_id=payload.get("document_id", 0), chunk_id=chunk_id,
+                              start_idx=payload.get("start_char", 0), end_idx=payload.get("end_char", 0),
+                              text=payload.get("text", ""), metadata=payload, embedding=None), float(score)))
+        return out
+
+
+class PooledView:
+    """One collection of a ``PooledCollections`` behind the interface of the
+    reference's per-collection backend object (``QdrantSearchOptimizer``,
+    vector_db/search_optimizer.py:68-406): ``search`` / ``batch_search`` return
+    ``(Chunk, score)`` tuples best first and raise ``SearchError``."""
+
+    def __init__(self, pool: PooledCollections, config: SearchConfig):
+        if config.dimension != pool.dimension:
+            raise SearchError(f"pool holds vectors of dimension {pool.dimension}")
+        self.pool = pool
+        self.config = config
+        self.collection_name = config.collection_name
+        self.logger = logging.getLogger(__name__)
+        pool.ranges.setdefault(self.collection_name, [])
+        pool._rows.setdefault(self.collection_name, {})
+
+    @property
+    def index(self) -> DeviceIndex:
+        return self.pool.index
+
+    async def create_collection(self) -> bool:
+        return True
+
+    def upsert(self, vectors, payloads: Sequence[Dict[str, Any]], ids: Sequence[Any]) -> List[Any]:
+        try:
+            self.pool.upsert(self.collection_name, vectors, payloads, ids)
+        except ValueError as e:
+            raise SearchError(str(e))
+        return list(ids)
+
+    def get_vector(self, point_id) -> Optional[Dict[str, Any]]:
+        row = self.pool.row_of(self.collection_name, point_id)
+        if row is None:
+            return None
+        return {"id": point_id, "vector": self.pool.index.reconstruct([row])[0].tolist(),
+                "payload": self.pool.payloads[row], "row": row}
+
+    def row_of(self, point_id) -> Optional[int]:
+        return self.pool.row_of(self.collection_name, point_id)
+
+    def set_points_active(self, active: bool) -> None:
+        self.pool.set_collection_active(self.collection_name, active)
+
+    def search_sync(self, query_vector, limit: int = 10, min_score: float = 0.0,
+                    filters: Dict[str, Any] = None, search_params: Dict[str, Any] = None):
+        return self.batch_search_sync([query_vector], limit, min_score, filters, search_params)[0]
+
+    def batch_search_sync(self, query_vectors, limit: int = 10, min_score: float = 0.0,
+                          filters: Dict[str, Any] = None, search_params: Dict[str, Any] = None):
+        try:
+            if getattr(self, "_disabled", False):
+                return [[] for _ in query_vectors]
+            q = np.ascontiguousarray(query_vectors, dtype=np.float32)
+            if q.ndim != 2 or q.shape[1] != self.config.dimension:
+                raise ValueError(f"query vectors must have dimension {self.config.dimension}")
+            if limit < 1:
+                return [[] for _ in range(q.shape[0])]
+            names = [self.collection_name]
+            hits = self.pool.search_many(names, q, min(int(limit), 1024), min_score=min_score,
+                                         row_mask=self.pool.filter_mask(names, filters))
+            return [self.pool.chunks_of(hits[i][0]) for i in range(q.shape[0])]
+        except Exception as e:
+            self.logger.error(f"Search operation failed: {e}")
+            raise SearchError(f"Search failed: {e}")
+
+    async def search(self, query_vector: List[float], limit: int = 10, min_score: float = 0.0,
+                     filters: Dict[str, Any] = None, search_params: Dict[str, Any] = None
+                     ) -> List[Tuple[Chunk, float]]:
+        t0 = time.time()
+        out = self.search_sync(query_vector, limit, min_score, filters, search_params)
+        self.logger.debug(f"HIP search completed in {time.time() - t0:.4f} seconds, found {len(out)} results")
+        return out
+
+    async def batch_search(self, query_vectors: List[List[float]], limit: int = 10, min_score: float = 0.0,
+                           filters: Dict[str, Any] = None, search_params: Dict[str, Any] = None
+                           ) -> List[List[Tuple[Chunk, float]]]:
+        try:
+            return self.batch_search_sync(query_vectors, limit, min_score, filters, search_params)
+        except SearchError as e:
+            raise SearchError(f"Batch search failed: {e}")
+
+    async def get_collection_info(self) -> Dict[str, Any]:
+        live = self.pool.count(self.collection_name)
+        return {"name": self.collection_name, "vectors_count": live, "indexed_vectors_count": live,
+                "points_count": live, "segments_count": len(self.pool.ranges.get(self.collection_name, [])),
+                "config": {"vector_size": self.config.dimension, "distance": self.config.metric.value,
+                           "hnsw_config": None, "optimizer_config": {"backend": "hip", "path": "pooled-scan"}},
+                "status": "green"}
+
+    async def get_vector_count(self) -> int:
+        return self.pool.count(self.collection_name)
+
+    async def delete_collection(self) -> bool:
+        try:
+            self.pool.drop(self.collection_name)
+            return True
+        except Exception as e:
+            self.logger.error(f"Failed to delete collection: {e}")
+            return False
+
+    def validate_health(self) -> Dict[str, Any]:
+        live = self.pool.count(self.collection_name)
+        return {"status": "healthy", "collection_name": self.collection_name, "vectors_count": live,
+                "indexed_vectors_count": live, "collection_status": "green"}

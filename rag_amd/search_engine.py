@@ -36,16 +36,17 @@ class HipSearchEngine:
         :856-874 builds (full_query 0.4, concepts 0.6, expanded 0.3)."""
         try:
             per_doc, hits_by_key = [], {}
-            for doc_id in filters.document_ids or []:
-                index_name = f"doc_{doc_id}"
+            doc_ids = list(filters.document_ids or [])
+            # the documents x strategies fan-out as one call (one device pass on a pooled manager)
+            all_hits = await self.storage_manager.search_vectors_many(
+                [f"doc_{doc_id}" for doc_id in doc_ids], [vector for _name, vector, _weight in query_embeddings],
+                vector_type="content", limit=limit * 2, score_threshold=filters.min_score or 0.1,
+                metadata_filters={"user_id": filters.user_id} if filters.user_id else None)
+            for di, doc_id in enumerate(doc_ids):
                 strategies = []
-                for name, vector, weight in query_embeddings:
-                    hits = await self.storage_manager.search_vectors(
-                        index_name=index_name, query_vector=vector, vector_type="content", limit=limit * 2,
-                        score_threshold=filters.min_score or 0.1,
-                        metadata_filters={"user_id": filters.user_id} if filters.user_id else None)
+                for qi, (name, _vector, weight) in enumerate(query_embeddings):
                     pairs = []
-                    for h in hits:
+                    for h in all_hits[qi][di]:
                         cid = h.get("metadata", {}).get("chunk_id")
                         pairs.append((cid, h.get("score", 0.0)))
                         if cid:
@@ -75,10 +76,11 @@ class HipSearchEngine:
                                   ) -> List[SearchResult]:
         """search_manager.py:995-1017."""
         out = []
-        for doc_id in filters.document_ids or []:
-            hits = await self.storage_manager.contextual_search(
-                index_name=f"doc_{doc_id}", query_vector=query_vector, limit=limit * 2, content_weight=0.7,
-                context_weight=0.3, score_threshold=filters.min_score * 0.5 if filters.min_score else None)
+        doc_ids = list(filters.document_ids or [])
+        per_doc = await self.storage_manager.contextual_search_many(
+            [f"doc_{doc_id}" for doc_id in doc_ids], query_vector, limit=limit * 2, content_weight=0.7,
+            context_weight=0.3, score_threshold=filters.min_score * 0.5 if filters.min_score else None)
+        for hits in per_doc:
             for h in hits:
                 res = _result_from_hit(h)
                 if res is not None:

@@ -18,14 +18,21 @@ from typing import Any, Dict, List, Optional, Tuple
 
 from . import fusion
 from .schemas import MetricType, SearchConfig
+from .pooled import PooledCollections, PooledView
 from .search_optimizer import HipSearchOptimizer
 
 logger = logging.getLogger(__name__)
 
 
 class VectorStorageManager:
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, pooled: bool = False):
+        """``pooled=True`` keeps every collection of one vector type and dimension as
+        row ranges of one device corpus, so that ``search_vectors_many`` answers a
+        whole per-document fan-out in one device pass; the objects registered in
+        ``search_optimizers`` are then views of those pools."""
         self.device = device
+        self.pooled = pooled
+        self._pools: Dict[Tuple[str, int], PooledCollections] = {}
         self.search_optimizers: Dict[str, HipSearchOptimizer] = {}
         self.content_collection_suffix = "_content"
         self.context_collection_suffix = "_context"
@@ -45,13 +52,20 @@ class VectorStorageManager:
         """storage_manager.py:162-252: two COSINE collections and their optimizers."""
         try:
             content_collection, context_collection = self._get_collection_names(index_name)
-            for key, name in ((f"{index_name}_content", content_collection),
-                              (f"{index_name}_context", context_collection)):
+            for key, name, vtype in ((f"{index_name}_content", content_collection, "content"),
+                                     (f"{index_name}_context", context_collection, "context")):
                 if key in self.search_optimizers:
                     continue
                 cfg = SearchConfig(dimension=embedding_dimension, metric=MetricType.COSINE,
                                    collection_name=name, device=self.device)
-                self.search_optimizers[key] = HipSearchOptimizer(config=cfg)
+                if self.pooled:
+                    pool = self._pools.get((vtype, embedding_dimension))
+                    if pool is None:
+                        pool = self._pools[(vtype, embedding_dimension)] = PooledCollections(
+                            embedding_dimension, metric="cosine", device=self.device)
+                    self.search_optimizers[key] = PooledView(pool, cfg)
+                else:
+                    self.search_optimizers[key] = HipSearchOptimizer(config=cfg)
             self._collections_state[index_name] = {"content": content_collection, "context": context_collection,
                                                    "dimension": embedding_dimension, "user_id": user_id,
                                                    "document_id": document_id}
@@ -108,20 +122,72 @@ class VectorStorageManager:
                 raise ValueError(f"Search optimizer '{optimizer_key}' not found. Available: {available}")
             results = await optimizer.search(query_vector=query_vector, limit=limit,
                                              min_score=score_threshold or 0.0, filters=metadata_filters)
-            formatted = []
-            for chunk, score in results:
-                metadata = {"chunk_id": getattr(chunk, "chunk_id", "unknown"),
-                            "document_id": getattr(chunk, "document_id", None),
-                            "start_char": getattr(chunk, "start_idx", None),
-                            "end_char": getattr(chunk, "end_idx", None)}
-                if getattr(chunk, "metadata", None):
-                    metadata.update(chunk.metadata)
-                formatted.append({"score": float(score), "content": chunk.text or "", "metadata": metadata,
-                                  "source": "hip"})
-            return formatted
+            return self._format_hits(results)
         except Exception as e:
             logger.error(f"Failed to search vectors in index {index_name}: {e}")
             return []
+
+    @staticmethod
+    def _format_hits(results) -> List[Dict[str, Any]]:
+        """storage_manager.py:477-505: (Chunk, score) tuples as result dictionaries."""
+        formatted = []
+        for chunk, score in results:
+            metadata = {"chunk_id": getattr(chunk, "chunk_id", "unknown"),
+                        "document_id": getattr(chunk, "document_id", None),
+                        "start_char": getattr(chunk, "start_idx", None),
+                        "end_char": getattr(chunk, "end_idx", None)}
+            if getattr(chunk, "metadata", None):
+                metadata.update(chunk.metadata)
+            formatted.append({"score": float(score), "content": chunk.text or "", "metadata": metadata,
+                              "source": "hip"})
+        return formatted
+
+    async def search_vectors_many(self, index_names: List[str], query_vectors: List[List[float]],
+                                  vector_type: str = "content", limit: int = 10, score_threshold: float = None,
+                                  metadata_filters: Dict[str, Any] = None) -> List[List[List[Dict[str, Any]]]]:
+        """``out[qi][ni]`` = what ``search_vectors(index_names[ni], query_vectors[qi], ...)``
+        returns, for every pair at once: the loop of vector_db/search_manager.py:879-913
+        (documents x query strategies, one RPC each in the reference) as one device
+        pass per pool (pooled manager) or one batched device call per index."""
+        out = [[[] for _ in index_names] for _ in query_vectors]
+        try:
+            if not index_names or not len(query_vectors):
+                return out
+            min_score = score_threshold or 0.0
+            by_pool: Dict[int, Tuple[PooledCollections, List[Tuple[int, PooledView]]]] = {}
+            for ni, index_name in enumerate(index_names):
+                optimizer = self.search_optimizers.get(f"{index_name}_{vector_type}")
+                if not optimizer:
+                    logger.error(f"Failed to search vectors in index {index_name}: "
+                                 f"Search optimizer '{index_name}_{vector_type}' not found")
+                    continue
+                if isinstance(optimizer, PooledView):
+                    if not getattr(optimizer, "_disabled", False):
+                        by_pool.setdefault(id(optimizer.pool), (optimizer.pool, []))[1].append((ni, optimizer))
+                    continue
+                try:
+                    lists = await optimizer.batch_search(query_vectors, limit=limit, min_score=min_score,
+                                                         filters=metadata_filters)
+                    for qi, results in enumerate(lists):
+                        out[qi][ni] = self._format_hits(results)
+                except Exception as e:
+                    logger.error(f"Failed to search vectors in index {index_name}: {e}")
+            for pool, members in by_pool.values():
+                if limit < 1:
+                    continue
+                names = [view.collection_name for _ni, view in members]
+                try:
+                    hits = pool.search_many(names, query_vectors, min(int(limit), 1024), min_score=min_score,
+                                            row_mask=pool.filter_mask(names, metadata_filters))
+                    for qi in range(len(hits)):
+                        for (ni, _view), h in zip(members, hits[qi]):
+                            out[qi][ni] = self._format_hits(pool.chunks_of(h))
+                except Exception as e:
+                    logger.error(f"Failed to search vectors in indexes {names[:3]}...: {e}")
+            return out
+        except Exception as e:
+            logger.error(f"Failed to search vectors in {len(index_names)} indexes: {e}")
+            return out
 
     async def get_vector_by_chunk_id(self, chunk_id: str) -> Optional[Dict[str, Any]]:
         """storage_manager.py:558-602: first collection (content before context, in
@@ -159,29 +225,57 @@ class VectorStorageManager:
             context_results = await self.search_vectors(index_name=index_name, query_vector=query_vector,
                                                         vector_type="context", limit=limit * 2,
                                                         metadata_filters=metadata_filters)
-            by_id: Dict[str, Dict[str, Any]] = {}
-            for r in content_results:
-                cid = r["metadata"].get("chunk_id")
-                if cid:
-                    by_id[cid] = r
-            for r in context_results:
-                cid = r["metadata"].get("chunk_id")
-                if cid and cid not in by_id:
-                    by_id[cid] = r
-            fused = fusion.contextual_fuse([(r["metadata"].get("chunk_id"), r["score"]) for r in content_results],
-                                           [(r["metadata"].get("chunk_id"), r["score"]) for r in context_results],
-                                           limit, content_weight, context_weight, score_threshold)
-            out = []
-            for cid, combined, cs, xs, _src in fused:
-                result = by_id[cid].copy()
-                result["score"] = combined
-                result["content_score"] = cs
-                result["context_score"] = xs
-                out.append(result)
-            return out
+            return self._fuse_contextual(content_results, context_results, limit, content_weight, context_weight,
+                                         score_threshold)
         except Exception as e:
             logger.error(f"Failed to perform contextual search in index {index_name}: {e}", exc_info=True)
             return []
+
+    @staticmethod
+    def _fuse_contextual(content_results, context_results, limit, content_weight, context_weight, score_threshold):
+        """storage_manager.py:653-709: union on chunk id, weighted sum, cut."""
+        by_id: Dict[str, Dict[str, Any]] = {}
+        for r in content_results:
+            cid = r["metadata"].get("chunk_id")
+            if cid:
+                by_id[cid] = r
+        for r in context_results:
+            cid = r["metadata"].get("chunk_id")
+            if cid and cid not in by_id:
+                by_id[cid] = r
+        fused = fusion.contextual_fuse([(r["metadata"].get("chunk_id"), r["score"]) for r in content_results],
+                                       [(r["metadata"].get("chunk_id"), r["score"]) for r in context_results],
+                                       limit, content_weight, context_weight, score_threshold)
+        out = []
+        for cid, combined, cs, xs, _src in fused:
+            result = by_id[cid].copy()
+            result["score"] = combined
+            result["content_score"] = cs
+            result["context_score"] = xs
+            out.append(result)
+        return out
+
+    async def contextual_search_many(self, index_names: List[str], query_vector: List[float], limit: int = 10,
+                                     content_weight: float = 0.7, context_weight: float = 0.3,
+                                     score_threshold: float = None, metadata_filters: Dict[str, Any] = None
+                                     ) -> List[List[Dict[str, Any]]]:
+        """``out[ni]`` = ``contextual_search(index_names[ni], query_vector, ...)`` for every
+        index: the per-document loop of vector_db/search_manager.py:995-1017 with the
+        content searches of all documents in one device pass and the context
+        searches in another."""
+        try:
+            content = await self.search_vectors_many(index_names, [query_vector], "content", limit * 2, None,
+                                                     metadata_filters)
+            present = [n for n in index_names if f"{n}_context" in self.search_optimizers]
+            context = await self.search_vectors_many(present, [query_vector], "context", limit * 2, None,
+                                                     metadata_filters)
+            ctx_of = dict(zip(present, context[0])) if present else {}
+            return [self._fuse_contextual(content[0][ni], ctx_of.get(name, []), limit, content_weight,
+                                          context_weight, score_threshold)
+                    for ni, name in enumerate(index_names)]
+        except Exception as e:
+            logger.error(f"Failed to perform contextual search in {len(index_names)} indexes: {e}", exc_info=True)
+            return [[] for _ in index_names]
 
     # --------------------------------------------------------- delete / restore
     async def delete_index(self, index_name: str, db=None) -> bool:
@@ -259,6 +353,9 @@ class VectorStorageManager:
             await self.delete_index(name)
         self.search_optimizers.clear()
         self._collections_state.clear()
+        for pool in self._pools.values():
+            pool.close()
+        self._pools.clear()
         self._is_initialized = False
 
 

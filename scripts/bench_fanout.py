@@ -29,14 +29,16 @@ def unit(n, dd=d):
 
 
 mgr = VectorStorageManager()
+pmgr = VectorStorageManager(pooled=True)
 pool = PooledCollections(d, metric="cosine")
 for doc in range(ndocs):
     n = int(rng.integers(50, 400))
     x = unit(n)
     ids = [f"doc_{doc}_chunk_{i}" for i in range(n)]
     meta = [{"document_id": doc} for _ in range(n)]
-    run(mgr.create_index(f"doc_{doc}", d))
-    run(mgr.add_vectors(f"doc_{doc}", x.tolist(), x.tolist(), meta, ids))
+    for m in (mgr, pmgr):
+        run(m.create_index(f"doc_{doc}", d))
+        run(m.add_vectors(f"doc_{doc}", x.tolist(), x.tolist(), meta, ids))
     pool.upsert(f"doc_{doc}", x, [dict(m, chunk_id=c) for m, c in zip(meta, ids)], ids)
 Q = unit(3)
 names = [f"doc_{doc}" for doc in range(ndocs)]
@@ -62,6 +64,28 @@ for fn in (loop_fanout, pooled_fanout):
     for _ in range(reps):
         fn()
     res[fn.__name__ + "_ms"] = (time.perf_counter() - t0) / reps * 1e3
+
+# the same fan-out through the engine method (search + formatting + max-fusion), per-collection and pooled manager
+from rag_amd.schemas import SearchFilters
+from rag_amd.search_engine import HipSearchEngine
+strat = [("full_query", Q[0].tolist(), 0.4), ("concepts", Q[1].tolist(), 0.6), ("expanded", Q[2].tolist(), 0.3)]
+filt = SearchFilters(document_ids=list(range(ndocs)), min_score=None)
+for label, m in (("engine_semantic_search_per_collection_ms", mgr), ("engine_semantic_search_pooled_ms", pmgr)):
+    eng = HipSearchEngine(m)
+    first = run(eng.semantic_search(strat, filt, limit))
+    t0 = time.perf_counter()
+    for _ in range(5):
+        run(eng.semantic_search(strat, filt, limit))
+    res[label] = (time.perf_counter() - t0) / 5 * 1e3
+    res[label[:-3] + "_top"] = [r.chunk_id for r in first[:3]]
+
+# the device call alone (H2D of queries and ranges, one scan pass, D2H of the lists)
+segs = [tuple(r) for nme in names for r in pool.ranges[nme]]
+pool.index.search_segments(Q, segs, 2 * limit, min_score=0.1)
+t0 = time.perf_counter()
+for _ in range(20):
+    pool.index.search_segments(Q, segs, 2 * limit, min_score=0.1)
+res["pooled_device_call_ms"] = (time.perf_counter() - t0) / 20 * 1e3
 
 # fusion + MMR on 200 candidates of a 1M x 768 corpus
 n, dd = 1_000_000, 768

@@ -74,3 +74,93 @@ def test_pooled_collections_equal_per_index_loop():
     assert len(pool.ranges["doc_3"]) == 2
     run(mgr.cleanup())
     pool.close()
+
+
+def _strip(hits):
+    return [(h["metadata"]["chunk_id"], h["metadata"].get("document_id"), h["content"], h["source"]) for h in hits]
+
+
+def test_pooled_manager_answers_like_the_per_collection_manager():
+    """Every public search of the storage manager and the engine's two fan-outs
+    (vector_db/search_manager.py:879-913, :995-1017) on a pooled manager against the
+    manager that keeps one device index per collection."""
+    from rag_amd.pooled import PooledView
+    from rag_amd.schemas import SearchFilters
+    from rag_amd.search_engine import HipSearchEngine
+    from rag_amd.storage_manager import VectorStorageManager
+    run = asyncio.get_event_loop().run_until_complete
+    rng = np.random.default_rng(47)
+    d = 384
+    plain, pooled = VectorStorageManager(), VectorStorageManager(pooled=True)
+    docs = list(range(1, 31))
+    for doc in docs:
+        n = int(rng.integers(3, 250))
+        content, context = _unit(rng, n, d), _unit(rng, n, d)
+        ids = [f"doc_{doc}_chunk_{i}" for i in range(n)]
+        meta = [{"document_id": doc, "text": f"{doc}/{i}", "user_id": 7 if (doc + i) % 3 else 8, "page": i}
+                for i in range(n)]
+        for m in (plain, pooled):
+            assert run(m.create_index(f"doc_{doc}", d))
+            assert run(m.add_vectors(f"doc_{doc}", content.tolist(), context.tolist(), meta, ids)) == ids
+    assert all(isinstance(o, PooledView) for o in pooled.search_optimizers.values())
+    assert len(pooled._pools) == 2                                  # one pool per vector type
+    # replace three points of document 4 and append to document 9 (second row range in the pool)
+    rep = _unit(rng, 3, d)
+    rids = [f"doc_4_chunk_{i}" for i in range(3)]
+    extra = _unit(rng, 5, d)
+    eids = [f"doc_9_chunk_x{i}" for i in range(5)]
+    for m in (plain, pooled):
+        run(m.add_vectors("doc_4", rep.tolist(), rep.tolist(), [{"document_id": 4, "text": "v2", "user_id": 7}] * 3, rids))
+        run(m.add_vectors("doc_9", extra.tolist(), extra.tolist(), [{"document_id": 9, "user_id": 7}] * 5, eids))
+    Q = _unit(rng, 3, d)
+
+    def same(a, b):
+        assert _strip(a) == _strip(b)
+        assert np.allclose([h["score"] for h in a], [h["score"] for h in b], rtol=1e-6, atol=1e-7)
+
+    for filt in (None, {"user_id": 7}, {"user_id": 7, "page": {"range": {"gte": 2, "lt": 40}}}):
+        for name in ("doc_4", "doc_9", "doc_17", "doc_missing"):
+            for vtype in ("content", "context"):
+                same(run(pooled.search_vectors(name, Q[0].tolist(), vtype, limit=12, score_threshold=0.02, metadata_filters=filt)),
+                     run(plain.search_vectors(name, Q[0].tolist(), vtype, limit=12, score_threshold=0.02, metadata_filters=filt)))
+            got = run(pooled.contextual_search(name, Q[1].tolist(), limit=8, metadata_filters=filt))
+            want = run(plain.contextual_search(name, Q[1].tolist(), limit=8, metadata_filters=filt))
+            same(got, want)
+            assert [h["score"] for h in got] == pytest.approx([h["score"] for h in want], rel=1e-6)
+    # the many-variants equal the loops, on both managers
+    names = [f"doc_{doc}" for doc in docs] + ["doc_missing"]
+    for m in (plain, pooled):
+        many = run(m.search_vectors_many(names, Q.tolist(), "content", 10, 0.05, {"user_id": 7}))
+        ctx = run(m.contextual_search_many(names, Q[2].tolist(), limit=6, score_threshold=0.01))
+        for ni, name in enumerate(names):
+            for qi in range(3):
+                same(many[qi][ni], run(plain.search_vectors(name, Q[qi].tolist(), "content", limit=10, score_threshold=0.05,
+                                                            metadata_filters={"user_id": 7})))
+            same(ctx[ni], run(plain.contextual_search(name, Q[2].tolist(), limit=6, score_threshold=0.01)))
+    # engine fan-outs
+    strat = [("full_query", Q[0].tolist(), 0.4), ("concepts", Q[1].tolist(), 0.6), ("expanded", Q[2].tolist(), 0.3)]
+    filt = SearchFilters(user_id=7, document_ids=docs + [999], min_score=None)
+    a, b = (run(HipSearchEngine(m).semantic_search(strat, filt, 10)) for m in (pooled, plain))
+    assert len(a) == 10
+    assert [(r.document_id, r.chunk_id, r.metadata["search_strategy"]) for r in a] == \
+           [(r.document_id, r.chunk_id, r.metadata["search_strategy"]) for r in b]
+    assert np.allclose([r.score for r in a], [r.score for r in b], rtol=1e-6)
+    a, b = (run(HipSearchEngine(m).contextual_semantic(Q[0].tolist(), filt, 5)) for m in (pooled, plain))
+    assert [(r.document_id, r.chunk_id) for r in a] == [(r.document_id, r.chunk_id) for r in b] and len(a) > 50
+    # vector fetch, soft delete / restore, delete
+    va, vb = (run(m.get_vector_by_chunk_id("doc_4_chunk_1")) for m in (pooled, plain))
+    assert va["source"] == vb["source"] and np.array_equal(va["vector"], vb["vector"])
+    for m in (plain, pooled):
+        assert run(m.soft_delete_index("doc_17"))
+    assert run(pooled.search_vectors("doc_17", Q[0].tolist(), limit=5)) == []
+    assert run(pooled.search_vectors_many(["doc_17", "doc_4"], Q[:1].tolist(), limit=5))[0][0] == []
+    for m in (plain, pooled):
+        assert run(m.restore_index("doc_17"))
+    same(run(pooled.search_vectors("doc_17", Q[0].tolist(), limit=5)), run(plain.search_vectors("doc_17", Q[0].tolist(), limit=5)))
+    assert run(pooled.delete_index("doc_9")) and "doc_9_content" not in pooled.search_optimizers
+    assert run(pooled.search_vectors("doc_9", Q[0].tolist(), limit=5)) == []
+    assert run(pooled.create_index("doc_9", d)) and run(pooled.search_vectors("doc_9", Q[0].tolist(), limit=5)) == []
+    stats = run(pooled.get_index_stats("doc_4"))
+    assert stats["collections"]["content"]["points_count"] == run(plain.get_index_stats("doc_4"))["collections"]["content"]["points_count"]
+    run(plain.cleanup())
+    run(pooled.cleanup())
