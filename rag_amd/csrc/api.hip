@@ -354,6 +354,7 @@ int rag_index_free(rag_index_t* h) {
 int rag_index_reserve(rag_index_t* h, int64_t nrows) {
     if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
     if (nrows < 0) return fail(RAG_ERR_INVALID, "nrows < 0");
+    RAG_LOCK_INDEX(h);
     DeviceGuard g(h->device);
     h->reserve_hint = nrows;
     if (nrows > h->cap && !h->adopted) return ensure_rows(h, nrows - h->n);
@@ -367,6 +368,7 @@ static int add_common(rag_index_t* h, int64_t n, const float* x, bool x_on_devic
     if (!x) return fail(RAG_ERR_INVALID, "x is NULL");
     if (h->n + n > 0x7FFFFFF0LL) return fail(RAG_ERR_UNSUPPORTED, "more than 2^31 rows per index");
     if (h->kind == RAG_KIND_IVF && h->ivf.nlist == 0) return fail(RAG_ERR_INVALID, "IVF index must be trained before rows are added");
+    RAG_LOCK_INDEX(h);
     DeviceGuard g(h->device);
     if (int rc = ws_acquire(h, h->stream)) return rc;
     if (int rc = ensure_rows(h, n)) return rc;
@@ -410,6 +412,7 @@ int rag_index_adopt_device(rag_index_t* h, int64_t n, float* x_dev) {
     if (h->dim % 4 != 0) return fail(RAG_ERR_INVALID, "adopt needs dim % 4 == 0");
     if ((reinterpret_cast<uintptr_t>(x_dev) & 15) != 0) return fail(RAG_ERR_INVALID, "adopt needs a 16-byte aligned buffer");
     if (n > 0x7FFFFFF0LL) return fail(RAG_ERR_UNSUPPORTED, "more than 2^31 rows per index");
+    RAG_LOCK_INDEX(h);
     DeviceGuard g(h->device);
     if (h->metric == RAG_METRIC_COSINE && n > 0) {
         RAG_HIP_CHECK(launch_ingest_rows(x_dev, n, h->dim, h->ld, 1, x_dev, h->stream));
@@ -430,6 +433,7 @@ int rag_index_profile_enable(rag_index_t* h, int enable) {
 
 int rag_index_profile_read(rag_index_t* h, double* kernel_ms, int64_t* launches, int reset) {
     if (!h || !kernel_ms || !launches) return fail(RAG_ERR_INVALID, "NULL argument");
+    RAG_LOCK_INDEX(h);
     DeviceGuard g(h->device);
     double total = 0.0;
     for (size_t i = 0; i + 1 < h->prof_used; i += 2) {
@@ -448,6 +452,7 @@ int rag_index_set_prefilter(rag_index_t* h, int mode) {
     if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
     if (mode != 0 && mode != 1) return fail(RAG_ERR_INVALID, "prefilter mode must be 0 (off) or 1 (bf16 first pass)");
     if (mode == 1 && h->kind != RAG_KIND_FLAT) return fail(RAG_ERR_UNSUPPORTED, "the bf16 first pass needs a FLAT index");
+    RAG_LOCK_INDEX(h);
     DeviceGuard g(h->device);
     if (mode == 0 && h->Xb) {
         if (int rc = ws_acquire(h, h->stream)) return rc;
@@ -462,6 +467,7 @@ int rag_index_set_prefilter(rag_index_t* h, int mode) {
 
 int rag_index_set_id_base(rag_index_t* h, int64_t base) {
     if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
+    RAG_LOCK_INDEX(h);
     h->id_base = base;
     return RAG_OK;
 }
@@ -476,6 +482,7 @@ int rag_index_set_active(rag_index_t* h, int64_t n, const int64_t* rows, int act
     if (n == 0) return RAG_OK;
     for (int64_t i = 0; i < n; ++i)
         if (rows[i] < 0 || rows[i] >= h->n) return fail(RAG_ERR_INVALID, "row " + std::to_string(rows[i]) + " out of range");
+    RAG_LOCK_INDEX(h);
     DeviceGuard g(h->device);
     if (!h->active) {
         if (active) return RAG_OK;   // everything is active already
@@ -498,6 +505,7 @@ int rag_index_reconstruct(rag_index_t* h, int64_t n, const int64_t* rows, float*
     if (n == 0) return RAG_OK;
     for (int64_t i = 0; i < n; ++i)
         if (rows[i] < 0 || rows[i] >= h->n) return fail(RAG_ERR_INVALID, "row " + std::to_string(rows[i]) + " out of range");
+    RAG_LOCK_INDEX(h);
     DeviceGuard g(h->device);
     const size_t rbytes = ((size_t)n * sizeof(long long) + 255) & ~(size_t)255;
     if (int rc = ws_acquire(h, h->stream)) return rc;
@@ -529,6 +537,7 @@ int rag_index_search_device(rag_index_t* h, int64_t nq, const float* q_dev, int 
     if (nq == 0) return RAG_OK;
     if (!q_dev || !D_dev || !I_dev) return fail(RAG_ERR_INVALID, "NULL buffer");
     if (min_score != min_score) return fail(RAG_ERR_INVALID, "min_score is NaN");
+    RAG_LOCK_INDEX(h);
     DeviceGuard g(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc = ws_acquire(h, s)) return rc;
@@ -583,6 +592,7 @@ int rag_index_search(rag_index_t* h, int64_t nq, const float* q, int k, float mi
     if (k < 1 || k > 1024) return fail(RAG_ERR_INVALID, "k must be in [1, 1024]");
     if (nq == 0) return RAG_OK;
     if (!q || !D || !I) return fail(RAG_ERR_INVALID, "NULL buffer");
+    RAG_LOCK_INDEX(h);
     DeviceGuard g(h->device);
     // staging in a separate allocation from the search workspaces
     static thread_local Workspace stage[64];
@@ -622,6 +632,7 @@ int rag_index_search_segments(rag_index_t* h, int64_t nq, const float* q, int64_
             return fail(RAG_ERR_INVALID, "segment " + std::to_string(i) + " is not a row range of the index");
         rows_total += seg_end[i] - seg_begin[i];
     }
+    RAG_LOCK_INDEX(h);
     DeviceGuard g(h->device);
     hipStream_t s = h->stream;
     if (int rc = ws_acquire(h, s)) return rc;

@@ -379,6 +379,7 @@ int rag_mmr_select(int64_t n, int d, const void* emb, int emb_is_f64, const doub
 int rag_mmr_select_rows(rag_index_t* h, int64_t n, const int64_t* rows, const double* rel, double lambda,
                         double similarity_threshold, int metric, int max_results, int32_t* out_idx, int32_t* n_out) {
     if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
+    RAG_LOCK_INDEX(h);
     if (n > 0 && !rows) return fail(RAG_ERR_INVALID, "rows is NULL");
     for (int64_t i = 0; i < n; ++i)
         if (rows[i] < 0 || rows[i] >= h->n) return fail(RAG_ERR_INVALID, "row " + std::to_string(rows[i]) + " out of range");

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -60,6 +61,8 @@ struct IvfState {
 
 }  // namespace rag
 
+#define RAG_LOCK_INDEX(h) std::lock_guard<std::recursive_mutex> rag_index_lock_((h)->mu)
+
 struct rag_index {
     int dim = 0;
     int ld = 0;          // row stride in floats, multiple of 4
@@ -90,6 +93,10 @@ struct rag_index {
     const char* last_path = "none";
     rag::IvfState ivf;
     // measurement: event pairs around the dominant kernel of each search
+    // every entry point that takes the index holds this while it runs on the host (enqueues, copies,
+    // bookkeeping), so host threads may share an index; device work of consecutive calls is ordered
+    // by ws_acquire / ws_release
+    std::recursive_mutex mu;
     bool profiling = false;
     std::vector<hipEvent_t> prof_events;   // start, stop, start, stop, ...
     size_t prof_used = 0;

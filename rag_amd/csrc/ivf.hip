@@ -251,6 +251,7 @@ using namespace rag;
 
 extern "C" int rag_index_train_ivf(rag_index_t* h, int nlist, const float* centroids, int64_t nsample, const float* sample) {
     if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
+    RAG_LOCK_INDEX(h);
     if (h->kind != RAG_KIND_IVF) return fail(RAG_ERR_INVALID, "not an IVF index");
     if (h->n != 0) return fail(RAG_ERR_INVALID, "train before adding rows");
     if (nlist < 1 || nlist > (1 << 22)) return fail(RAG_ERR_INVALID, "nlist must be in [1, 4194304]");

@@ -36,6 +36,7 @@ struct FileCloser {
 
 extern "C" int rag_index_save(rag_index_t* h, const char* path) {
     if (!h || !path) return fail(RAG_ERR_INVALID, "NULL argument");
+    RAG_LOCK_INDEX(h);
     if (h->kind != RAG_KIND_FLAT) return fail(RAG_ERR_UNSUPPORTED, "snapshots cover FLAT indexes");
     FILE* f = fopen(path, "wb");
     if (!f) return fail(RAG_ERR_INVALID, std::string("cannot open for writing: ") + path);

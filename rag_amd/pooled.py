@@ -147,6 +147,8 @@ class PooledCollections:
             if hit is None or hit[0] != self._version:
                 rows = np.fromiter((r for r in self._rows.get(name, {}).values()
                                     if payload_passes(self.payloads[r], filters)), dtype=np.int64)
+                if len(self._mask_cache) >= 65536:           # bounded: start over rather than grow
+                    self._mask_cache.clear()
                 self._mask_cache[(name, fkey)] = hit = (self._version, rows)
             mask[hit[1]] = 1
         return mask
@@ -197,6 +199,23 @@ class PooledCollections:
             out.append((Chunk(document_id=payload.get("document_id", 0), chunk_id=chunk_id,
                               start_idx=payload.get("start_char", 0), end_idx=payload.get("end_char", 0),
                               text=payload.get("text", ""), metadata=payload, embedding=None), float(score)))
+        return out
+
+
+    def hit_dicts(self, hits: Sequence[Tuple[int, float]]) -> List[Dict[str, Any]]:
+        """(row, score) pairs as the result dictionaries of
+        vector_db/storage_manager.py:477-505 -- what formatting ``chunks_of(hits)``
+        gives, without the intermediate objects."""
+        out = []
+        for row, score in hits:
+            payload = self.payloads[row] or {}
+            metadata = {"chunk_id": payload.get("chunk_id") or str(self.point_ids[row]),
+                        "document_id": payload.get("document_id", 0),
+                        "start_char": payload.get("start_char", 0), "end_char": payload.get("end_char", 0)}
+            if payload:
+                metadata.update(payload)
+            out.append({"score": float(score), "content": payload.get("text", "") or "", "metadata": metadata,
+                        "source": "hip"})
         return out
 
 

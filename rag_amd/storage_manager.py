@@ -181,7 +181,7 @@ class VectorStorageManager:
                                             row_mask=pool.filter_mask(names, metadata_filters))
                     for qi in range(len(hits)):
                         for (ni, _view), h in zip(members, hits[qi]):
-                            out[qi][ni] = self._format_hits(pool.chunks_of(h))
+                            out[qi][ni] = pool.hit_dicts(h)
                 except Exception as e:
                     logger.error(f"Failed to search vectors in indexes {names[:3]}...: {e}")
             return out

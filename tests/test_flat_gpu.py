@@ -300,3 +300,53 @@ def test_gather_slot_layout_and_strided_merge():
         _check(Dm.cpu().numpy(), Im.cpu().numpy(), X, Q, k)
         for sh in shards:
             sh.close()
+
+
+def test_host_threads_may_share_an_index():
+    """The reference's callers reach the backend from several threads (the MMR
+    thread pool of vector_db/mmr_diversifier.py:58, uvicorn workers): entry points
+    that take an index serialise on it, so concurrent calls give the answers of
+    sequential ones."""
+    import threading
+    from rag_amd import DeviceIndex
+    rng = np.random.default_rng(77)
+    n, d = 60000, 384
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    idx = DeviceIndex(d, metric="ip")
+    idx.add(X)
+    jobs = []
+    for t in range(6):
+        nq = (1, 3, 9, 40, 1, 2)[t]
+        jobs.append((rng.standard_normal((nq, d)).astype(np.float32), (10, 100, 10, 20, 200, 5)[t]))
+    want = [idx.search(q, k) for q, k in jobs]
+    segs = [(0, 1000), (1000, 30000), (30000, n)]
+    want_seg = idx.search_segments(jobs[1][0], segs, 7)
+    errors = []
+
+    def work(t):
+        try:
+            q, k = jobs[t]
+            for _ in range(25):
+                D, I = idx.search(q, k)
+                if not (np.array_equal(I, want[t][1]) and np.array_equal(D, want[t][0])):
+                    errors.append(("search", t))
+                if t == 1:
+                    Ds, Is = idx.search_segments(q, segs, 7)
+                    if not (np.array_equal(Is, want_seg[1]) and np.array_equal(Ds, want_seg[0])):
+                        errors.append(("segments", t))
+                if t == 4:
+                    v = idx.reconstruct([5, 59999])
+                    if not np.array_equal(v, X[[5, 59999]]):
+                        errors.append(("reconstruct", t))
+        except Exception as e:                                   # noqa: BLE001
+            errors.append(("raised", t, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(6)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(120)
+    assert not any(th.is_alive() for th in threads)
+    assert errors == []
+    idx.close()
