@@ -7,9 +7,11 @@
  * declaration names the reference interface it stands in for (paths relative to
  * the reference tree).  Host pointers unless a parameter is named *_dev.
  *
- * Threading: calls on different indexes are independent; searches on one index
- * are serialised by the caller (they share the index's workspace); add / free
- * must not overlap a search on the same index.
+ * Threading: every entry point that takes an index holds that index's mutex for
+ * the host side of the call, so host threads may share an index (their calls are
+ * serialised); calls on different indexes are independent; the fusion and MMR
+ * entry points keep per-thread workspaces.  rag_index_free must not overlap
+ * another call on the same index.
  */
 #ifndef RAG_HIP_H
 #define RAG_HIP_H
@@ -124,7 +126,8 @@ int rag_index_search_device(rag_index_t* h, int64_t nq, const float* q_dev, int 
 int rag_index_search_segments(rag_index_t* h, int64_t nq, const float* q, int64_t nseg,
                               const int64_t* seg_begin, const int64_t* seg_end, int k,
                               float min_score, const uint8_t* row_mask, float* D, int64_t* I);
-/* which kernel the last search on this index used ("scan", "gemm", "ivf", "segments") */
+/* which kernel path the last search on this index used ("scan", "gemm", "ivf", "ivf-listmajor",
+ * "segments", "scan-bf16", "gemm-bf16") */
 const char* rag_index_last_path(const rag_index_t* h);
 
 /* multi-GPU step after the all-gather of per-shard results: merge `nlists`

@@ -1,0 +1,168 @@
+/*
+ * A host program in plain C against include/rag_hip.h: what a non-Python caller
+ * (a cgo / JNI / C++ host) does with the library.  Builds a small corpus, checks
+ * rag_index_search against a brute-force loop, exercises segments, soft delete,
+ * reconstruct, the IVF entry points, score fusion, MMR and the error convention.
+ * Exit code 0 = every check passed; prints the first failure otherwise.
+ *
+ *   gcc -O2 -std=c11 -I include tests/c_abi/host_check.c -o tests/c_abi/host_check \
+ *       -L rag_amd -lrag_hip -Wl,-rpath,'$ORIGIN/../../rag_amd' -lm
+ */
+#include <float.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "rag_hip.h"
+
+#define CHECK(cond, ...)                                  \
+    do {                                                  \
+        if (!(cond)) {                                    \
+            fprintf(stderr, "FAILED %s:%d: ", __FILE__, __LINE__); \
+            fprintf(stderr, __VA_ARGS__);                 \
+            fprintf(stderr, " [%s]\n", rag_last_error()); \
+            return 1;                                     \
+        }                                                 \
+    } while (0)
+
+static unsigned long long rng_state = 0x9E3779B97F4A7C15ull;
+static float frand(void) { /* xorshift, uniform in [-1, 1) */
+    rng_state ^= rng_state << 13;
+    rng_state ^= rng_state >> 7;
+    rng_state ^= rng_state << 17;
+    return (float)((rng_state >> 40) / 8388608.0 - 1.0);
+}
+
+/* exact top-k by insertion: score descending, lower row first */
+static void brute(const float* X, int n, int d, const float* q, int lo, int hi, const unsigned char* mask, float min_score,
+                  int k, float* D, long long* I) {
+    for (int j = 0; j < k; ++j) { D[j] = -FLT_MAX; I[j] = -1; }
+    (void)n;
+    for (int r = lo; r < hi; ++r) {
+        if (mask && !mask[r]) continue;
+        double acc = 0.0;
+        for (int c = 0; c < d; ++c) acc += (double)X[(size_t)r * d + c] * q[c];
+        float s = (float)acc;
+        if (s < min_score) continue;
+        int pos = k;
+        while (pos > 0 && (I[pos - 1] < 0 || s > D[pos - 1])) --pos;
+        if (pos == k) continue;
+        for (int j = k - 1; j > pos; --j) { D[j] = D[j - 1]; I[j] = I[j - 1]; }
+        D[pos] = s;
+        I[pos] = r;
+    }
+}
+
+static int same_hits(const float* D, const int64_t* I, const float* Dr, const long long* Ir, int k) {
+    for (int j = 0; j < k; ++j) {
+        if (I[j] != Ir[j]) {
+            /* a different row is fine only when the scores tie within the fp32 tolerance */
+            if (I[j] < 0 || Ir[j] < 0 || fabsf(D[j] - Dr[j]) > 1e-5f * fabsf(Dr[j]) + 1e-6f) return 0;
+        } else if (I[j] >= 0 && fabsf(D[j] - Dr[j]) > 1e-5f * fabsf(Dr[j]) + 1e-6f) {
+            return 0;
+        }
+    }
+    return 1;
+}
+
+int main(void) {
+    int ndev = 0;
+    CHECK(rag_version() == RAG_ABI_VERSION, "ABI version");
+    CHECK(rag_device_count(&ndev) == RAG_OK && ndev >= 1, "no device");
+
+    const int n = 20000, d = 128, nq = 7, k = 10;
+    float* X = malloc((size_t)n * d * sizeof(float));
+    float* Q = malloc((size_t)nq * d * sizeof(float));
+    CHECK(X && Q, "malloc");
+    for (size_t i = 0; i < (size_t)n * d; ++i) X[i] = frand();
+    for (size_t i = 0; i < (size_t)nq * d; ++i) Q[i] = frand();
+
+    /* error convention: status code + message, nothing thrown, nothing written */
+    rag_index_t* h = NULL;
+    CHECK(rag_index_create(0, RAG_METRIC_IP, RAG_KIND_FLAT, 0, &h) == RAG_ERR_INVALID && h == NULL, "dim 0 accepted");
+    CHECK(strlen(rag_last_error()) > 0, "no message");
+    CHECK(rag_index_create(d, RAG_METRIC_IP, RAG_KIND_FLAT, 0, &h) == RAG_OK && h, "create");
+    CHECK(rag_index_add(h, n / 2, X, NULL) == RAG_OK, "add 1");
+    CHECK(rag_index_add(h, n - n / 2, X + (size_t)(n / 2) * d, NULL) == RAG_OK, "add 2");
+    CHECK(rag_index_ntotal(h) == n && rag_index_dim(h) == d, "ntotal / dim");
+
+    float D[7 * 10], Dr[10];
+    int64_t I[7 * 10];
+    long long Ir[10];
+    CHECK(rag_index_search(h, nq, Q, 0, 0.f, 1, NULL, D, I) == RAG_ERR_INVALID, "k = 0 accepted");
+    CHECK(rag_index_search(h, nq, Q, k, -FLT_MAX, 1, NULL, D, I) == RAG_OK, "search");
+    for (int qi = 0; qi < nq; ++qi) {
+        brute(X, n, d, Q + (size_t)qi * d, 0, n, NULL, -FLT_MAX, k, Dr, Ir);
+        CHECK(same_hits(D + qi * k, I + qi * k, Dr, Ir, k), "query %d differs from the brute-force scan", qi);
+    }
+    /* one query, a threshold and a byte mask */
+    unsigned char* mask = malloc(n);
+    for (int r = 0; r < n; ++r) mask[r] = (unsigned char)(r % 3 != 0);
+    CHECK(rag_index_search(h, 1, Q, k, 1.0f, 1, mask, D, I) == RAG_OK, "masked search");
+    brute(X, n, d, Q, 0, n, mask, 1.0f, k, Dr, Ir);
+    CHECK(same_hits(D, I, Dr, Ir, k), "masked query differs");
+
+    /* soft delete hides rows, restore brings them back */
+    brute(X, n, d, Q, 0, n, NULL, -FLT_MAX, k, Dr, Ir);
+    int64_t best = Ir[0];
+    CHECK(rag_index_set_active(h, 1, &best, 0) == RAG_OK, "set_active 0");
+    CHECK(rag_index_search(h, 1, Q, k, -FLT_MAX, 1, NULL, D, I) == RAG_OK && I[0] == Ir[1], "hidden row returned");
+    CHECK(rag_index_set_active(h, 1, &best, 1) == RAG_OK, "set_active 1");
+    CHECK(rag_index_search(h, 1, Q, k, -FLT_MAX, 1, NULL, D, I) == RAG_OK && I[0] == Ir[0], "restored row missing");
+
+    /* segments: the k best of every (query, row range) pair in one pass */
+    int64_t sb[3] = {0, 5000, 19990}, se[3] = {5000, 19990, 20000};
+    float Ds[2 * 3 * 10];
+    int64_t Is[2 * 3 * 10];
+    CHECK(rag_index_search_segments(h, 2, Q, 3, sb, se, k, -FLT_MAX, NULL, Ds, Is) == RAG_OK, "segments");
+    for (int qi = 0; qi < 2; ++qi)
+        for (int s = 0; s < 3; ++s) {
+            brute(X, n, d, Q + (size_t)qi * d, (int)sb[s], (int)se[s], NULL, -FLT_MAX, k, Dr, Ir);
+            CHECK(same_hits(Ds + (qi * 3 + s) * k, Is + (qi * 3 + s) * k, Dr, Ir, k), "segment (%d, %d) differs", qi, s);
+        }
+    se[2] = 20001;
+    CHECK(rag_index_search_segments(h, 2, Q, 3, sb, se, k, -FLT_MAX, NULL, Ds, Is) == RAG_ERR_INVALID, "bad range accepted");
+
+    /* reconstruct returns the stored rows bit for bit */
+    int64_t rows[2] = {3, 19999};
+    float back[2 * 128];
+    CHECK(rag_index_reconstruct(h, 2, rows, back) == RAG_OK, "reconstruct");
+    CHECK(memcmp(back, X + 3 * d, d * sizeof(float)) == 0 && memcmp(back + d, X + (size_t)19999 * d, d * sizeof(float)) == 0,
+          "reconstructed rows differ");
+
+    /* MMR over rows of the index: lambda 1 is the relevance order */
+    int64_t cand[5];
+    double rel[5] = {0.2, 1.0, 0.0, 0.7, 0.5};
+    for (int j = 0; j < 5; ++j) cand[j] = I[j];
+    int32_t pick[5], npick = 0;
+    CHECK(rag_mmr_select_rows(h, 5, cand, rel, 1.0, 0.8, RAG_MMR_COSINE, 3, pick, &npick) == RAG_OK, "mmr rows");
+    CHECK(npick == 3 && pick[0] == 1 && pick[1] == 3 && pick[2] == 4, "mmr order %d %d %d", pick[0], pick[1], pick[2]);
+    CHECK(rag_index_free(h) == RAG_OK, "free");
+
+    /* IVF: every list probed = the exhaustive answer */
+    const int nlist = 16;
+    CHECK(rag_index_create(d, RAG_METRIC_IP, RAG_KIND_IVF, 0, &h) == RAG_OK, "create ivf");
+    CHECK(rag_index_train_ivf(h, nlist, X, 0, NULL) == RAG_OK, "train");       /* the first 16 rows are the centroids */
+    CHECK(rag_index_add(h, n, X, NULL) == RAG_OK, "ivf add");
+    CHECK(rag_index_search(h, nq, Q, k, -FLT_MAX, nlist, NULL, D, I) == RAG_OK, "ivf search");
+    for (int qi = 0; qi < nq; ++qi) {
+        brute(X, n, d, Q + (size_t)qi * d, 0, n, NULL, -FLT_MAX, k, Dr, Ir);
+        CHECK(same_hits(D + qi * k, I + qi * k, Dr, Ir, k), "ivf query %d differs", qi);
+    }
+    CHECK(strncmp(rag_index_last_path(h), "ivf", 3) == 0, "path %s", rag_index_last_path(h));
+    CHECK(rag_index_free(h) == RAG_OK, "free ivf");
+
+    /* content / context fusion: 0.7 a + 0.3 b, threshold, stable order */
+    double a[4] = {0.9, 0.5, 0.0, 0.5}, b[4] = {0.0, 0.8, 0.4, 0.8}, out[4];
+    int32_t order[4], nout = 0;
+    CHECK(rag_fuse_weighted(4, a, b, 0.7, 0.3, 1, 0.2, 3, order, out, &nout) == RAG_OK, "fuse");
+    CHECK(nout == 3 && order[0] == 0 && order[1] == 1 && order[2] == 3, "fusion order");
+    CHECK(out[0] == 0.9 * 0.7 + 0.0 * 0.3 && out[1] == 0.5 * 0.7 + 0.8 * 0.3 && out[2] == 0.0 * 0.7 + 0.4 * 0.3, "fusion scores");
+
+    free(X);
+    free(Q);
+    free(mask);
+    printf("c abi host check: ok\n");
+    return 0;
+}
