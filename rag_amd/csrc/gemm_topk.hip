@@ -79,7 +79,16 @@ constexpr int GEMM_MAX_K = 64;
 // The narrow shapes trigger at 64 keys for k <= 32 and at 128 above (a trigger below 2k would
 // compact after every tile); their buffers are sized for the larger one.
 __host__ __device__ constexpr int gemm_trig_max(int RT, int QT) { return QT >= 128 ? RT : 128; }
-__host__ __device__ constexpr int gemm_trig(int RT, int QT, int k) { return QT >= 128 ? RT : (k <= 32 ? 64 : 128); }
+// Wide shapes (QT >= 128): the threshold of a query only moves when its buffer is compacted, so a
+// late trigger leaves it stale -- with 256 the k-th best of the first 256 rows stood for the next 6000
+// rows and every tile pushed a dozen candidates per wave.  Triggering at about 3k keeps the threshold
+// within a factor of ~3 of the current one; the sort of a compaction then covers 64 or 128 keys.
+// The bf16 pass carries every key within the margin of the k-th best across a compaction (a few times k
+// on unstructured data), so it triggers later.
+__host__ __device__ constexpr int gemm_trig(int RT, int QT, int k, bool b16 = false) {
+    return QT >= 128 ? (b16 ? (k <= 16 ? 128 : RT) : (k <= 16 ? 32 : (k <= 32 ? 64 : 128)))
+                     : (k <= 32 ? 64 : 128);
+}
 __host__ __device__ constexpr int gemm_capq(int RT, int QT) { return gemm_trig_max(RT, QT) + RT; }
 
 // Timing-only ablations for diagnostic builds (outputs are wrong when non-zero):
@@ -109,6 +118,7 @@ struct GemmArgs {
     int nqb_pad;     // query blocks rounded up for the XCD-friendly decode
     int S;           // row ranges
     int gq;          // placement: query-block groups across the 8 XCDs (0: plain b % nqb_pad decode)
+    int trig;        // a query's buffer is compacted once it holds more keys than this (gemm_trig)
     // list-major IVF scan (TASKS): a work item = up to QT queries that probe one list
     const int* total_tasks;        // device: number of work items
     const int* task_list;          // [tasks] list of the work item
@@ -119,9 +129,11 @@ struct GemmArgs {
     const int* pair_slot;          // [pairs] where the pair's k keys go in part (slot * k)
     const long long* list_begin;   // [nlist + 1] rows of a list (storage order)
     const long long* row_alias;    // storage position -> row number reported in keys (NULL: identity)
-    // fp32 pass: the best k-th score any row range has reached so far, per query (ordered-float bits,
-    // 0 = none yet).  Every workgroup of a query raises it when it compacts and reads it once per tile:
-    // a row scoring below another range's k-th best cannot be in the answer.
+    // the best k-th score any row range has reached so far, per query (ordered-float bits, 0 = none
+    // yet).  Every workgroup of a query raises it when it compacts and reads it once per tile: a row
+    // scoring below another range's k-th best cannot be in the answer.  The bf16 pass publishes its
+    // k-th best approximate score minus the margin, below which no range needs to keep a row (and
+    // which also lies below the exact k-th best, so the fp32 fallback may start from it).
     unsigned int* gthr;
 };
 
@@ -142,7 +154,7 @@ __device__ __forceinline__ void push_candidate(const GemmArgs& a, u64* cand, int
     if (row < row_hi && (!a.mask || a.mask[row])) {
         const int pos = atomicAdd(&s_cnt[ql], 1);
         cand[(size_t)ql * CAPQ + pos] = make_key(sc, (uint32_t)(a.row_alias ? a.row_alias[row] : row));
-        if (pos + 1 > gemm_trig(RT, QT, a.k)) *s_flag = 1;       // compact before the next tile can overflow it
+        if (pos + 1 > a.trig) *s_flag = 1;       // compact before the next tile can overflow it
     }
 }
 
@@ -166,9 +178,8 @@ __device__ __forceinline__ int count_above(const u64* sorted, int n, float thr, 
 // tighten the threshold
 template <int RT, int QT, int NW, bool B16>
 __device__ __forceinline__ void compact_queries(u64* scratch, u64* cand, int* s_cnt, float* s_thr, const float* s_margin,
-                                                int* overflow, unsigned int* gthr, int k, int wave, int lane) {
+                                                int* overflow, unsigned int* gthr, int k, int TRIG, int wave, int lane) {
     constexpr int CAPQ = gemm_capq(RT, QT);
-    const int TRIG = gemm_trig(RT, QT, k);
     for (int ql = wave; ql < QT; ql += NW) {
         const int c = s_cnt[ql];
         if (c <= TRIG) continue;            // wave-uniform
@@ -192,7 +203,7 @@ __device__ __forceinline__ void compact_queries(u64* scratch, u64* cand, int* s_
             s_cnt[ql] = keep;
             if (c >= k) {
                 s_thr[ql] = thr;
-                if (!B16 && gthr) atomicMax(&gthr[ql], f32_ordered(thr));
+                if (gthr) atomicMax(&gthr[ql], f32_ordered(thr));
             }
         }
         SyncWave()();
@@ -200,38 +211,40 @@ __device__ __forceinline__ void compact_queries(u64* scratch, u64* cand, int* s_
 }
 
 // Tile epilogue.  A lane owns NJ queries and 2 x 16 scores of each.  First the cheap test "does
-// any of my scores beat its query's threshold" (a max tree and one ballot); only a wave
-// with a hit walks its accumulators.  rbase = first corpus row of this wave's 64, qbase =
-// first query (within the block) of this wave's NJ * 32.
+// one of my 16-score groups beat its query's threshold" (a max tree per group, one ballot per
+// group); the wave walks only the groups in which some lane has a hit -- a wave meets about one
+// candidate per tile for most of a row range, so it walks 16 accumulators, not all 32 * NJ.
+// rbase = first corpus row of this wave's 64, qbase = first query (within the block) of this
+// wave's NJ * 32.
 template <int RT, int QT, int NJ>
 __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f16v (&acc)[2][NJ], u64* cand, float* s_thr, int* s_cnt,
                                               int* s_flag, int m_valid, long long rbase, long long row_hi, int qbase, int l31, int h,
                                               const float (&tg)[NJ]) {
     float thr[NJ];
-    bool hit = false;
+    bool hit[2][NJ];
 #pragma unroll
     for (int nj = 0; nj < NJ; ++nj) {
         const int ql = qbase + nj * 32 + l31;
         thr[nj] = ql < m_valid ? s_thr[ql] : INFINITY;
-        float m = -INFINITY;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < 2; ++mi) {
+            float m = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[mi][nj][r]);
-        hit |= m > thr[nj] && m >= tg[nj];      // a tie with another range's k-th best may still win on row number
+            hit[mi][nj] = m > thr[nj] && m >= tg[nj];      // a tie with another range's k-th best may still win on row number
+        }
     }
-    if (__ballot(hit) != 0ull) {
 #pragma unroll
-        for (int nj = 0; nj < NJ; ++nj) {
-            const int ql = qbase + nj * 32 + l31;
+    for (int nj = 0; nj < NJ; ++nj) {
+        const int ql = qbase + nj * 32 + l31;
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < 2; ++mi) {
+            if (__ballot(hit[mi][nj]) == 0ull) continue;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float sc = acc[mi][nj][r];
-                    if (sc > thr[nj] && sc >= tg[nj])
-                        push_candidate<RT, QT>(a, cand, s_cnt, s_flag, ql, rbase + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, row_hi, sc);
-                }
+            for (int r = 0; r < 16; ++r) {
+                const float sc = acc[mi][nj][r];
+                if (sc > thr[nj] && sc >= tg[nj])
+                    push_candidate<RT, QT>(a, cand, s_cnt, s_flag, ql, rbase + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, row_hi, sc);
             }
         }
     }
@@ -398,7 +411,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
         for (int kt = 0; kt < KT; ++kt, buf ^= 1) {
             if (!(DIAG & 4) || (t == t_begin && kt < 2))
                 __syncthreads();     // stage `buf` is complete (the LDS-DMA in flight is drained here too)
-            if constexpr (!B16 && !TASKS) {
+            if constexpr (!TASKS) {
                 if (kt == KT - 1 && a.gthr) {
 #pragma unroll
                     for (int nj = 0; nj < NJ; ++nj) {
@@ -414,7 +427,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
             // passed the barrier above, so the flag is stable and stage buf^1 is idle
             if (kt == 0 && *s_flag != 0) {
                 compact_queries<RT, QT, NW, B16>(reinterpret_cast<u64*>(As + (buf ^ 1) * TILEA) + wave * CAPQ2, cand, s_cnt, s_thr, s_margin,
-                                                 a.overflow, (!B16 && !TASKS && a.gthr) ? a.gthr + q0 : nullptr, k, wave, lane);
+                                                 a.overflow, (!TASKS && a.gthr) ? a.gthr + q0 : nullptr, k, a.trig, wave, lane);
                 __syncthreads();
                 if (tid == 0) *s_flag = 0;
             }
@@ -786,6 +799,10 @@ int gemm_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float
     a.S = p.S;
     a.gq = p.gq;
     a.outc = k;
+    static const int trig_env = env_int_g("RAG_GEMM_TRIG", 0);          // measurement only
+    const int plan_rt = (p.QT == 256 || p.QT == 32) ? 256 : 128;
+    a.trig = gemm_trig(plan_rt, p.QT, k);
+    if (trig_env > 0 && p.QT >= 128) a.trig = std::min(trig_env, plan_rt);
     const int grid = p.nqb_pad * p.S;
     // workspace: [queries | candidate buffers | partial keys | bf16 queries | margins | kept keys | flag]
     const size_t qbytes = ((size_t)nq * h->ld * sizeof(float) + 255) & ~(size_t)255;
@@ -829,6 +846,7 @@ int gemm_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float
         b.margin = margin;
         b.overflow = flag;
         b.outc = pref_outc(p.S);
+        b.trig = gemm_trig(256, 256, k, true);
         if (int rc = profile_begin(h, s)) return rc;
         if (int rc = launch_gemm<256, 256, 8, true>(b, grid, h->device, s)) return rc;
         if (int rc = profile_end(h, s)) return rc;
@@ -987,6 +1005,7 @@ int ivf_listmajor_scan(rag_index* h, long long nq, const float* qbuf, int k, flo
     a.ld = h->ld;
     a.k = k;
     a.outc = k;
+    a.trig = gemm_trig(256, 32, k);
     a.total_tasks = total;
     a.task_list = task_list;
     a.task_begin = task_begin;
