@@ -141,6 +141,11 @@ struct GemmArgs {
 #ifndef RAG_B16_SCHED
 #define RAG_B16_SCHED 1
 #endif
+// which kernels hand K steps over in front of the last block of MFMAs: bit 0 fp32, bit 1 bf16 pass,
+// bit 2 also the narrow shapes
+#ifndef RAG_GEMM_HANDOVER
+#define RAG_GEMM_HANDOVER 1
+#endif
 #ifndef RAG_GEMM_NARROW_AUX
 #define RAG_GEMM_NARROW_AUX 2
 #endif
@@ -268,6 +273,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
     // cache policy of the corpus loads: a single query block reads every row once (non-temporal,
     // bit 1); with many query blocks the rows are re-read by other workgroups and should stay cached
     constexpr int A_AUX = (QT >= 128) ? 0 : RAG_GEMM_NARROW_AUX;
+    // hand-over of K steps in front of a step's last block of MFMAs (see the K loop)
+    constexpr bool HO = !TASKS && ((RAG_GEMM_HANDOVER & (B16 ? 2 : 1)) != 0) && (QT >= 128 || (RAG_GEMM_HANDOVER & 4) != 0);
     static_assert(WM * WQ == NW && NJ >= 1 && WM * 64 == RT && WQ * NJ * 32 == QT && APW >= 1 && BPW >= 1, "tile shape");
     static_assert(NW * CAPQ2 * 8 <= TILEA * 4, "compaction scratch must fit in one idle corpus stage");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -408,9 +415,37 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
         float tg[NJ];
 #pragma unroll
         for (int nj = 0; nj < NJ; ++nj) tg[nj] = -INFINITY;
+        // fragments of k block kb+1 are requested while the MFMAs of block kb issue (two register
+        // sets, kb parity).  Issue order, fixed with sched_group_barrier: per block [MFMAs, 1 read]
+        // until the next block's reads are out, then the rest of the block's MFMAs -- every read has
+        // most of a block to land.
+        constexpr int READS = 2 + NJ, MFMAS = 8 * NJ, NKB = GK / 8;
+        f4 fa[2][2], fb[2][NJ];
         for (int kt = 0; kt < KT; ++kt, buf ^= 1) {
-            if (!(DIAG & 4) || (t == t_begin && kt < 2))
-                __syncthreads();     // stage `buf` is complete (the LDS-DMA in flight is drained here too)
+            const float* Ab = As + buf * TILEA + (wm * 64) * GK;
+            const float* Bb = Bs + buf * TILEB + (wq * NJ * 32) * GK;
+            if (!HO || kt == 0) {
+                if (!(DIAG & 4) || (t == t_begin && kt < 2))
+                    __syncthreads();     // stage `buf` is complete (the LDS-DMA in flight is drained here too)
+                // a candidate buffer filled up during the previous tile's epilogue: every wave has
+                // passed the barrier above, so the flag is stable and stage buf^1 is idle
+                if (kt == 0 && *s_flag != 0) {
+                    compact_queries<RT, QT, NW, B16>(reinterpret_cast<u64*>(As + (buf ^ 1) * TILEA) + wave * CAPQ2, cand, s_cnt, s_thr, s_margin,
+                                                     a.overflow, (!TASKS && a.gthr) ? a.gthr + q0 : nullptr, k, a.trig, wave, lane);
+                    __syncthreads();
+                    if (tid == 0) *s_flag = 0;
+                }
+                if (!(DIAG & 2) || (t == t_begin && kt == 0)) {
+                    if (DIAG & 1024) issue_load(0, buf ^ 1);       // same instructions, cache-resident source
+                    else if (kt + 1 < KT) issue_load(kt + 1, buf ^ 1);
+                    else if (t + 1 < t_end) { set_tile(t + 1); issue_load(0, buf ^ 1); }
+                }
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) fa[0][mi] = *reinterpret_cast<const f4*>(Ab + mi * 32 * GK + foff[0]);
+#pragma unroll
+                for (int nj = 0; nj < NJ; ++nj) fb[0][nj] = *reinterpret_cast<const f4*>(Bb + nj * 32 * GK + foff[0]);
+                if (!B16 || RAG_B16_SCHED) __builtin_amdgcn_sched_group_barrier(0x100, READS, 0);
+            }
             if constexpr (!TASKS) {
                 if (kt == KT - 1 && a.gthr) {
 #pragma unroll
@@ -423,40 +458,32 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
                     }
                 }
             }
-            // a candidate buffer filled up during the previous tile's epilogue: every wave has
-            // passed the barrier above, so the flag is stable and stage buf^1 is idle
-            if (kt == 0 && *s_flag != 0) {
-                compact_queries<RT, QT, NW, B16>(reinterpret_cast<u64*>(As + (buf ^ 1) * TILEA) + wave * CAPQ2, cand, s_cnt, s_thr, s_margin,
-                                                 a.overflow, (!TASKS && a.gthr) ? a.gthr + q0 : nullptr, k, a.trig, wave, lane);
-                __syncthreads();
-                if (tid == 0) *s_flag = 0;
-            }
-            if (!(DIAG & 2) || (t == t_begin && kt == 0)) {
-                if (DIAG & 1024) issue_load(0, buf ^ 1);       // same instructions, cache-resident source
-                else if (kt + 1 < KT) issue_load(kt + 1, buf ^ 1);
-                else if (t + 1 < t_end) { set_tile(t + 1); issue_load(0, buf ^ 1); }
-            }
-            const float* Ab = As + buf * TILEA + (wm * 64) * GK;
-            const float* Bb = Bs + buf * TILEB + (wq * NJ * 32) * GK;
-            // fragments of k block kb+1 are requested while the MFMAs of block kb issue (two
-            // register sets, kb parity).  Issue order, fixed with sched_group_barrier: the reads of
-            // block 0, then per block [2 MFMAs, 1 read] until the next block's reads are out, then
-            // the rest of the block's MFMAs -- every read has most of a block to land.
-            constexpr int READS = 2 + NJ, MFMAS = 8 * NJ;
-            f4 fa[2][2], fb[2][NJ];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) fa[0][mi] = *reinterpret_cast<const f4*>(Ab + mi * 32 * GK + foff[0]);
-#pragma unroll
-            for (int nj = 0; nj < NJ; ++nj) fb[0][nj] = *reinterpret_cast<const f4*>(Bb + nj * 32 * GK + foff[0]);
-            if (!B16 || RAG_B16_SCHED) __builtin_amdgcn_sched_group_barrier(0x100, READS, 0);
-#pragma unroll
-            for (int kb = 0; kb < GK / 8; ++kb) {
+            for (int kb = 0; kb < NKB; ++kb) {
                 const int cur = kb & 1, nxt = cur ^ 1;
-                if (kb + 1 < GK / 8) {
+                bool reads = kb + 1 < NKB;
+                if (kb + 1 < NKB) {
 #pragma unroll
                     for (int mi = 0; mi < 2; ++mi) fa[nxt][mi] = *reinterpret_cast<const f4*>(Ab + mi * 32 * GK + foff[kb + 1]);
 #pragma unroll
                     for (int nj = 0; nj < NJ; ++nj) fb[nxt][nj] = *reinterpret_cast<const f4*>(Bb + nj * 32 * GK + foff[kb + 1]);
+                } else if (HO && kt + 1 < KT) {
+                    // hand-over to the next K step in front of this step's last block of MFMAs: the
+                    // fragments of that block are in registers, so after the barrier stage `buf` is free
+                    // for the step after next, and the first fragments of the next step (stage buf^1,
+                    // complete at this barrier) are read while those MFMAs run
+                    __syncthreads();
+                    if (!(DIAG & 2)) {
+                        if (kt + 2 < KT) issue_load(kt + 2, buf);
+                        else if (t + 1 < t_end) { set_tile(t + 1); issue_load(0, buf); }
+                    }
+                    const float* An = As + (buf ^ 1) * TILEA + (wm * 64) * GK;
+                    const float* Bn = Bs + (buf ^ 1) * TILEB + (wq * NJ * 32) * GK;
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) fa[nxt][mi] = *reinterpret_cast<const f4*>(An + mi * 32 * GK + foff[0]);
+#pragma unroll
+                    for (int nj = 0; nj < NJ; ++nj) fb[nxt][nj] = *reinterpret_cast<const f4*>(Bn + nj * 32 * GK + foff[0]);
+                    reads = true;
                 }
                 if constexpr (B16) {
                     // a 16-byte fragment is 8 bf16 = the whole K extent of one 32x32x16 MFMA
@@ -477,7 +504,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
                 }
                 if constexpr (B16 && RAG_B16_SCHED) {
                     // 2*NJ MFMAs per block: one read behind each of the first READS MFMAs
-                    if (kb + 1 < GK / 8) {
+                    if (reads) {
 #pragma unroll
                         for (int j = 0; j < READS; ++j) {
                             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -489,7 +516,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
                     }
                 }
                 if constexpr (!B16) {
-                    if (kb + 1 < GK / 8) {
+                    if (reads) {
 #pragma unroll
                         for (int j = 0; j < READS; ++j) {
                             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
