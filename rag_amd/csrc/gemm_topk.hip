@@ -985,8 +985,11 @@ static size_t lm_align(size_t b) { return (b + 255) & ~(size_t)255; }
 
 bool ivf_listmajor_supported(const rag_index* h, long long nq, int k, int nprobe) {
     static const int on = env_int_g("RAG_IVF_LISTMAJOR", 1);
+    // worth it once a list is probed by more than one query on average: (query, probe) pairs per list,
+    // in halves (measurement knob; default 1 pair per list: 256 queries x 64 probes over 16384 lists 9.2 -> 8.9 ms, half of that is slower)
+    static const int min_pairs_x2 = std::max(1, env_int_g("RAG_IVF_LISTMAJOR_PAIRS_X2", 2));
     const long long npairs = nq * (long long)nprobe;
-    return on && k <= GEMM_MAX_K && (h->ld % GK) == 0 && npairs >= 2LL * h->ivf.nlist && npairs < (1LL << 30);
+    return on && k <= GEMM_MAX_K && (h->ld % GK) == 0 && 2 * npairs >= (long long)min_pairs_x2 * h->ivf.nlist && npairs < (1LL << 30);
 }
 
 // bytes after the padded queries: [4 x nlist ints | total | work-item table | pair_q | pair_slot | cand | part]

@@ -55,7 +55,8 @@ t_pack = time.perf_counter() - t0
 flat = DeviceIndex(dim, metric="ip")
 flat.adopt(X)
 out = {"clustered_corpus": clustered, "rows": rows, "dim": dim, "nlist": nlist, "nprobe": nprobe, "add_assign_s": t_add, "first_search_pack_s": t_pack}
-for nq, steps in ((1, 50), (256, 5), (4096, 3)):
+batches = [int(b) for b in os.environ.get("BATCHES", "1,256,4096").split(",")]
+for nq, steps in [(b, 50 if b == 1 else (5 if b <= 512 else 3)) for b in batches]:
     ivf.profile(True)
     ivf.search(Q[:nq], k, nprobe=nprobe)
     torch.cuda.synchronize()

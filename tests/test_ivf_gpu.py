@@ -38,7 +38,7 @@ def test_ivf_matches_oracle(n, d, nlist, nprobe, nq, k):
     idx.add(X[n // 3:])
     D, I = idx.search(Q, k, nprobe=nprobe)
     # batches in which lists are probed by several queries take the list-major MFMA scan
-    listmajor = nq * nprobe >= 2 * nlist and k <= 64 and d % 32 == 0
+    listmajor = nq * nprobe >= nlist and k <= 64 and d % 32 == 0
     assert idx.last_path == ("ivf-listmajor" if listmajor else "ivf")
     _cmp(D, I, *ivf.ivf_search(X, C, Q, k, nprobe))
     # nprobe = nlist degenerates to the exhaustive answer
