@@ -20,17 +20,11 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
+from .filters import payload_passes
 from .index import DeviceIndex
 from .schemas import Chunk, IndexType, MetricType, SearchConfig, SearchError
 
 _METRIC = {MetricType.COSINE: "cosine", MetricType.DOT_PRODUCT: "ip"}
-
-
-def _match(value, wanted) -> bool:
-    """Qdrant MatchValue: equality, or membership when the payload field is a list."""
-    if isinstance(value, (list, tuple)):
-        return wanted in value
-    return value == wanted
 
 
 class HipSearchOptimizer:
@@ -50,6 +44,8 @@ class HipSearchOptimizer:
         self.point_ids: List[Any] = []                 # row position -> point id given at upsert
         self._row_of: Dict[Any, int] = {}              # point id -> live row position
         self._inactive = 0
+        self._version = 0                              # bumped by every change of the payload table
+        self._mask_cache: Dict[str, Tuple[int, np.ndarray]] = {}
 
     # ------------------------------------------------------------------ ingest
     async def create_collection(self) -> bool:
@@ -72,6 +68,7 @@ class HipSearchOptimizer:
             self.payloads.append(dict(p) if p else {})
             self.point_ids.append(i)
             self._row_of[i] = first + j
+        self._version += 1
         if stale:
             self.index.set_active(stale, False)
             self._inactive += len(set(stale))
@@ -98,37 +95,20 @@ class HipSearchOptimizer:
     def _mask(self, filters: Optional[Dict[str, Any]]) -> Optional[np.ndarray]:
         """search_optimizer.py:173-201: every condition must hold (Filter(must=...));
         a list value adds one equality condition per element; {'range': {...}}
-        is a numeric range; anything else is equality."""
+        is a numeric range; anything else is equality.  One byte per row; the
+        mask of a filter is kept until the collection changes, so the per-user
+        filter of every search (vector_db/search_manager.py:893) is evaluated once."""
         if not filters:
             return None
-        n = len(self.payloads)
-        mask = np.ones(n, dtype=np.uint8)
-        for key, value in filters.items():
-            if isinstance(value, list):
-                conds = [("eq", v) for v in value]
-            elif isinstance(value, dict) and "range" in value:
-                conds = [("range", value["range"])]
-            else:
-                conds = [("eq", value)]
-            for kind, arg in conds:
-                for r in range(n):
-                    if not mask[r]:
-                        continue
-                    pv = self.payloads[r].get(key)
-                    if kind == "eq":
-                        ok = pv is not None and _match(pv, arg)
-                    else:
-                        ok = isinstance(pv, (int, float)) and not isinstance(pv, bool)
-                        if ok and arg.get("gte") is not None:
-                            ok = pv >= arg["gte"]
-                        if ok and arg.get("lte") is not None:
-                            ok = pv <= arg["lte"]
-                        if ok and arg.get("gt") is not None:
-                            ok = pv > arg["gt"]
-                        if ok and arg.get("lt") is not None:
-                            ok = pv < arg["lt"]
-                    if not ok:
-                        mask[r] = 0
+        key = repr(sorted(filters.items(), key=lambda kv: kv[0]))
+        hit = self._mask_cache.get(key)
+        if hit is not None and hit[0] == self._version:
+            return hit[1]
+        mask = np.fromiter((payload_passes(p, filters) for p in self.payloads), dtype=np.uint8,
+                           count=len(self.payloads))
+        if len(self._mask_cache) >= 64:
+            self._mask_cache.clear()
+        self._mask_cache[key] = (self._version, mask)
         return mask
 
     def _to_chunks(self, D: np.ndarray, I: np.ndarray) -> List[Tuple[Chunk, float]]:
@@ -213,6 +193,8 @@ class HipSearchOptimizer:
         self.point_ids = meta["point_ids"]
         self._row_of = {self.point_ids[r]: r for r in meta["live_rows"]}
         self._inactive = 0
+        self._version = 0
+        self._mask_cache = {}
         return self
 
     # --------------------------------------------------------------- bookkeeping
@@ -231,6 +213,7 @@ class HipSearchOptimizer:
         try:
             self.index.close()
             self.payloads, self.point_ids, self._row_of = [], [], {}
+            self._version += 1
             return True
         except Exception as e:
             self.logger.error(f"Failed to delete collection: {e}")

@@ -113,3 +113,22 @@ def test_bm25_batch_scores_equal_scalar_scores_bitwise():
         batch = m.calculate_bm25_scores(terms, texts, stats)
         scalar = [m.calculate_bm25_score(terms, t or "", stats) for t in texts]
         assert batch == scalar
+
+
+def test_payload_filters_follow_the_reference_conditions():
+    """vector_db/search_optimizer.py:173-201: all conditions must hold; a list value is one
+    equality condition per element; {'range': ...} is numeric; a list payload matches by membership."""
+    from rag_amd.filters import payload_passes
+    p = {"user_id": 7, "tags": ["a", "b"], "page": 12, "flag": True, "name": "x"}
+    assert payload_passes(p, {"user_id": 7})
+    assert not payload_passes(p, {"user_id": 8})
+    assert not payload_passes(p, {"missing": 1})
+    assert payload_passes(p, {"tags": "a"}) and not payload_passes(p, {"tags": "c"})
+    assert payload_passes(p, {"tags": ["a", "b"]}) and not payload_passes(p, {"tags": ["a", "c"]})
+    assert payload_passes(p, {"page": {"range": {"gte": 12, "lte": 12}}})
+    assert not payload_passes(p, {"page": {"range": {"gt": 12}}})
+    assert not payload_passes(p, {"page": {"range": {"lt": 12}}})
+    assert not payload_passes(p, {"flag": {"range": {"gte": 0}}})          # booleans are not numbers here
+    assert not payload_passes(p, {"name": {"range": {"gte": 0}}})
+    assert payload_passes(p, {"user_id": 7, "page": {"range": {"gte": 1}}, "tags": "b"})
+    assert not payload_passes(p, {"user_id": 7, "page": {"range": {"gte": 13}}})
