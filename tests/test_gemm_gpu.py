@@ -30,7 +30,9 @@ def _check(D, I, X, Q, k, **kw):
     (40_000, 768, 9, 10), (40_000, 768, 32, 10), (40_001, 768, 33, 10), (25_000, 1024, 64, 64),
     (300, 64, 12, 10), (1_000, 256, 48, 3), (255, 384, 31, 10), (257, 384, 50, 64),
     # the 256 x 256 shape (8 waves) from 1024 queries
-    (20_000, 768, 1024, 10), (513, 1024, 1500, 64), (70_000, 384, 4096, 10)])
+    (20_000, 768, 1024, 10), (513, 1024, 1500, 64), (70_000, 384, 4096, 10),
+    # one, two and three K steps in the shapes whose K loop hands steps over early
+    (30_000, 32, 130, 10), (30_000, 64, 1100, 10), (30_000, 96, 200, 20), (2_000, 32, 1024, 64)])
 def test_gemm_matches_oracle(n, d, nq, k):
     from rag_amd import DeviceIndex
     rng = np.random.default_rng(n * 7 + d + nq)
