@@ -1085,7 +1085,7 @@ constexpr int PRE1_MAX = 1024;
 static int pre1_for(int k) { return k <= 16 ? 64 : 1024; }
 constexpr float PREF_ERR1 = 0.0021f;     // 2^-9 (rows rounded to bf16) + accumulation slack
 
-int scan_blocks(const rag_index* h);     // api.hip
+int scan_blocks(const rag_index* h, int k);     // api.hip
 
 struct VerifyArgs {
     const float* Dk;        // [npre] approximate scores, descending, -FLT_MAX padded
@@ -1161,14 +1161,14 @@ bool prefilter_scan_supported(const rag_index* h, long long nq, int k) {
 
 // after the padded query: [fp32 scan partial lists | bf16 scan partial lists | PRE1 scores | PRE1 rows | flag]
 size_t prefilter_scan_workspace(const rag_index* h, int k) {
-    const size_t blocks = (size_t)scan_blocks(h);
+    const size_t blocks = (size_t)scan_blocks(h, k);
     return 4 * blocks * k * sizeof(u64) + 256 + 4 * blocks * PRE1_MAX * sizeof(u64) + 256 + PRE1_MAX * 4 + PRE1_MAX * 8 + 256;
 }
 
 int prefilter_scan_search(rag_index* h, const float* qbuf, int k, float min_score, const uint8_t* mask,
                           float* D, long long* I, hipStream_t s) {
     if (int rc = prefilter_sync_rows(h, s)) return rc;
-    const int blocks = scan_blocks(h);
+    const int blocks = scan_blocks(h, k);
     const size_t qbytes = ((size_t)h->ld * sizeof(float) + 255) & ~(size_t)255;
     if (h->ws.bytes < qbytes + prefilter_scan_workspace(h, k))
         return fail(RAG_ERR_INVALID, "internal: workspace not sized for the bf16 scan");
