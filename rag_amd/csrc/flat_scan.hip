@@ -436,29 +436,42 @@ __global__ __launch_bounds__(1024) void merge_keys_small_kernel(MergeArgs a) {
     const long long q = blockIdx.x;
     const u64* in = a.keys + (size_t)q * a.per_query;
     u64 list = KEY_EMPTY, thr = KEY_EMPTY;
-    for (long long base = (long long)wave * 64; base < a.per_query; base += (long long)nw * 64) {
-        const long long i = base + lane;
-        const u64 key = i < a.per_query ? in[i] : KEY_EMPTY;
-        const bool cand = key > thr;
-        u64 m = __ballot(cand);
-        if (m == 0) continue;
-        if (__popcll(m) <= 6) {
-            while (m) {
-                const int j = __builtin_ctzll(m);
-                m &= m - 1;
-                const u64 kj = readlane_u64(key, j);
-                if (kj > thr) {
-                    wave_list_insert(list, kj, lane);
-                    thr = readlane_u64(list, k - 1);
+    // a wave's chunks of 64 keys are requested MU at a time before the first is looked at: the
+    // keys sit in L2 / HBM, and one dependent load per chunk made the latency of every chunk the
+    // cost of the merge (8 chunks per wave: 11 us; requested together: one latency)
+    constexpr int MU = 8;
+    const long long step = (long long)nw * 64;
+    for (long long base0 = (long long)wave * 64; base0 < a.per_query; base0 += step * MU) {
+        u64 keys[MU];
+#pragma unroll
+        for (int u = 0; u < MU; ++u) {
+            const long long i = base0 + u * step + lane;
+            keys[u] = i < a.per_query ? in[i] : KEY_EMPTY;
+        }
+#pragma unroll
+        for (int u = 0; u < MU; ++u) {
+            const u64 key = keys[u];
+            const bool cand = key > thr;
+            u64 m = __ballot(cand);
+            if (m == 0) continue;
+            if (__popcll(m) <= 6) {
+                while (m) {
+                    const int j = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const u64 kj = readlane_u64(key, j);
+                    if (kj > thr) {
+                        wave_list_insert(list, kj, lane);
+                        thr = readlane_u64(list, k - 1);
+                    }
                 }
+            } else {
+                // every producer writes descending runs of k keys, so with k = 64 the 64 keys a wave
+                // reads are one run, and cutting its tail at the threshold keeps it descending
+                u64 run = cand ? key : KEY_EMPTY;
+                if (k != 64) run = wave_sort_desc(run, lane);
+                list = wave_merge_top64(list, run, lane);
+                thr = readlane_u64(list, k - 1);
             }
-        } else {
-            // every producer writes descending runs of k keys, so with k = 64 the 64 keys a wave
-            // reads are one run, and cutting its tail at the threshold keeps it descending
-            u64 run = cand ? key : KEY_EMPTY;
-            if (k != 64) run = wave_sort_desc(run, lane);
-            list = wave_merge_top64(list, run, lane);
-            thr = readlane_u64(list, k - 1);
         }
     }
     s_lists[wave * 64 + lane] = list;
