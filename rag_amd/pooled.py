@@ -96,6 +96,49 @@ class PooledCollections:
         self._hidden.discard(name)
         self._version += 1
 
+    def dead_rows(self) -> int:
+        """Rows that no collection refers to any more (replaced points, dropped collections)."""
+        return len(self.payloads) - sum(len(r) for r in self._rows.values())
+
+    def compact(self) -> int:
+        """Rebuild the device corpus from the live rows, collection by collection (each
+        collection becomes one row range again); returns the number of rows released.
+        Dropped collections and replaced points only hide their rows
+        (vector_db/qdrant_client.py:826-883 keeps soft-deleted points too); this is the
+        vacuum step that gives their memory back."""
+        dead = self.dead_rows()
+        if dead == 0:
+            return 0
+        fresh = DeviceIndex(self.dimension, metric=self.index.metric, device=self.index.device)
+        payloads, point_ids, ranges, rows_of = [], [], {}, {}
+        hidden_rows = []
+        for name, rows in self._rows.items():
+            order = sorted(rows.items(), key=lambda kv: kv[1])          # insertion order within the collection
+            first = len(payloads)
+            if order:
+                old = [r for _pid, r in order]
+                for c0 in range(0, len(old), 65536):
+                    # COSINE rows were normalised on the way in; normalising them again moves an
+                    # element by one unit in the last place at most
+                    fresh.add(self.index.reconstruct(old[c0:c0 + 65536]))
+                for pid, r in order:
+                    rows_of.setdefault(name, {})[pid] = len(payloads)
+                    payloads.append(self.payloads[r])
+                    point_ids.append(pid)
+            rows_of.setdefault(name, {})
+            ranges[name] = [[first, len(payloads)]] if len(payloads) > first else []
+            if name in self._hidden:
+                hidden_rows.extend(range(first, len(payloads)))
+        for name in self.ranges:
+            ranges.setdefault(name, [])
+        if hidden_rows:
+            fresh.set_active(hidden_rows, False)
+        self.index.close()
+        self.index, self.payloads, self.point_ids, self.ranges, self._rows = fresh, payloads, point_ids, ranges, rows_of
+        self._version += 1
+        self._mask_cache.clear()
+        return dead
+
     def get_vector(self, name: str, point_id) -> Optional[np.ndarray]:
         row = self.row_of(name, point_id)
         return None if row is None else self.index.reconstruct([row])[0]

@@ -285,6 +285,12 @@ class VectorStorageManager:
                 if opt is not None:
                     await opt.delete_collection()
             self._collections_state.pop(index_name, None)
+            # a pooled corpus only hides the rows of a deleted collection: rebuild it once more
+            # than half of it (and at least 4096 rows) is dead
+            for pool in self._pools.values():
+                dead = pool.dead_rows()
+                if dead >= 4096 and 2 * dead > len(pool.payloads):
+                    pool.compact()
             return True
         except Exception as e:
             logger.error(f"Failed to delete index {index_name}: {e}")

@@ -164,3 +164,45 @@ def test_pooled_manager_answers_like_the_per_collection_manager():
     assert stats["collections"]["content"]["points_count"] == run(plain.get_index_stats("doc_4"))["collections"]["content"]["points_count"]
     run(plain.cleanup())
     run(pooled.cleanup())
+
+
+def test_pool_compaction_releases_dropped_rows_and_keeps_answers():
+    from rag_amd.pooled import PooledCollections
+    rng = np.random.default_rng(53)
+    d = 128
+    pool = PooledCollections(d, metric="cosine")
+    data = {}
+    for c in range(12):
+        n = int(rng.integers(20, 200))
+        x = _unit(rng, n, d) * rng.uniform(0.5, 2.0)
+        ids = [f"c{c}_{i}" for i in range(n)]
+        pool.upsert(f"c{c}", x, [{"chunk_id": i, "document_id": c} for i in ids], ids)
+        data[f"c{c}"] = ids
+    pool.upsert("c3", _unit(rng, 4, d), [{"chunk_id": i, "document_id": 3, "v": 2} for i in data["c3"][:4]], data["c3"][:4])
+    pool.upsert("c5", _unit(rng, 6, d), [{"chunk_id": f"c5_x{i}", "document_id": 5} for i in range(6)], [f"c5_x{i}" for i in range(6)])
+    pool.set_collection_active("c7", False)
+    for name in ("c0", "c9"):
+        pool.drop(name)
+    names = [f"c{c}" for c in range(12)]
+    Q = _unit(rng, 2, d)
+    flt = {"document_id": {"range": {"gte": 2}}}
+
+    def answers():
+        hits = pool.search_many(names, Q, 8, min_score=-1.0, row_mask=pool.filter_mask(names, flt))
+        return [[[(pool.payloads[r]["chunk_id"], pool.payloads[r].get("v"), s) for r, s in per] for per in qh] for qh in hits]
+
+    before, total = answers(), len(pool.payloads)
+    dead = pool.dead_rows()
+    assert dead == len(data["c0"]) + len(data["c9"]) + 4
+    assert pool.compact() == dead and pool.dead_rows() == 0 and len(pool.payloads) == total - dead
+    assert len(pool.index) == total - dead and all(len(r) <= 1 for r in pool.ranges.values())
+    after = answers()
+    for qb, qa in zip(before, after):
+        for pb, pa in zip(qb, qa):
+            assert [(c, v) for c, v, _ in pb] == [(c, v) for c, v, _ in pa]
+            assert np.allclose([s for *_x, s in pb], [s for *_x, s in pa], rtol=1e-6, atol=1e-7)
+    assert after[0][7] == [] and after[0][0] == []                      # hidden stays hidden, dropped stays gone
+    pool.set_collection_active("c7", True)
+    assert len(pool.search_many(["c7"], Q, 8, min_score=-1.0)[0][0]) == 8
+    assert pool.compact() == 0
+    pool.close()
