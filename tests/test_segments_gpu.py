@@ -206,3 +206,27 @@ def test_pool_compaction_releases_dropped_rows_and_keeps_answers():
     assert len(pool.search_many(["c7"], Q, 8, min_score=-1.0)[0][0]) == 8
     assert pool.compact() == 0
     pool.close()
+
+
+def test_pooled_manager_compacts_after_deletes():
+    from rag_amd.storage_manager import VectorStorageManager
+    run = asyncio.get_event_loop().run_until_complete
+    rng = np.random.default_rng(59)
+    d = 64
+    mgr = VectorStorageManager(pooled=True)
+    for doc in (1, 2, 3):
+        x = _unit(rng, 3000, d)
+        ids = [f"doc_{doc}_chunk_{i}" for i in range(3000)]
+        assert run(mgr.create_index(f"doc_{doc}", d))
+        assert run(mgr.add_vectors(f"doc_{doc}", x.tolist(), x.tolist(), [{"document_id": doc}] * 3000, ids)) == ids
+    q = _unit(rng, 1, d)[0].tolist()
+    before = run(mgr.search_vectors("doc_3", q, limit=10))
+    pool = mgr._pools[("content", d)]
+    assert len(pool.index) == 9000
+    assert run(mgr.delete_index("doc_1")) and len(pool.index) == 9000       # a third dead: left alone
+    assert run(mgr.delete_index("doc_2")) and len(pool.index) == 3000       # two thirds dead: rebuilt
+    after = run(mgr.search_vectors("doc_3", q, limit=10))
+    assert [h["metadata"]["chunk_id"] for h in after] == [h["metadata"]["chunk_id"] for h in before]
+    assert np.allclose([h["score"] for h in after], [h["score"] for h in before], rtol=1e-6, atol=1e-7)
+    assert run(mgr.get_vector_by_chunk_id("doc_3_chunk_5"))["source"] == "doc_3_content"
+    run(mgr.cleanup())
