@@ -9,6 +9,7 @@
 // candidate set never has to leave the GPU between search, fusion and MMR.
 #include <float.h>
 #include <math.h>
+#include <string.h>
 
 #include <vector>
 
@@ -134,97 +135,147 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     return v;
 }
 
-__global__ __launch_bounds__(1024) void mmr_kernel(MmrArgs p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double* s_wbest = reinterpret_cast<double*>(smem);          // [16]   header: 256 bytes
-    int* s_wbidx = reinterpret_cast<int*>(smem + 128);          // [16]
-    int& s_best = *reinterpret_cast<int*>(smem + 192);
-    double* maxsim = reinterpret_cast<double*>(smem + 256);     // [n]
-    int* alive = reinterpret_cast<int*>(maxsim + p.n);          // [n]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = p.n, d = p.d;
+// Per-launch state of the selection, in the workspace behind the outputs.
+struct MmrState {
+    double* maxsim;       // [n] largest similarity to any selected row so far
+    int* alive;           // [n] 1 = not selected yet
+    double* wg_best;      // [G] best marginal relevance of a workgroup's candidates this round
+    int* wg_bidx;         // [G] ... and its candidate (0x7FFFFFFF: none alive)
+    int* ctrl;            // [0] arrival counter of the round, [1] the row selected last
+};
 
-    // ---- rows as fp64; cosine: divided by their norm (a zero norm counts as 1) --------
-    for (int c = wave; c < n; c += 16) {
-        double ss = 0.0;
-        for (int j = lane; j < d; j += 64) {
-            double v;
-            if (p.X) v = (double)p.X[p.rows[c] * (long long)p.ld + j];
-            else if (p.emb_is_f64) v = static_cast<const double*>(p.emb)[(size_t)c * d + j];
-            else v = (double)static_cast<const float*>(p.emb)[(size_t)c * d + j];
-            p.En[(size_t)c * d + j] = v;
-            ss = fma(v, v, ss);
-        }
-        if (p.metric == RAG_MMR_COSINE) {
-            ss = wave_sum_f64(ss);
-            double nrm = sqrt(ss);
-            if (nrm == 0.0) nrm = 1.0;
-            for (int j = lane; j < d; j += 64) p.En[(size_t)c * d + j] = p.En[(size_t)c * d + j] / nrm;
-        }
+// rows as fp64; cosine: divided by their norm (a zero norm counts as 1).  One wave per row.
+__global__ __launch_bounds__(64) void mmr_prepare_kernel(MmrArgs p, MmrState st) {
+    const int lane = threadIdx.x, d = p.d;
+    const int c = blockIdx.x;
+    double ss = 0.0;
+    for (int j = lane; j < d; j += 64) {
+        double v;
+        if (p.X) v = (double)p.X[p.rows[c] * (long long)p.ld + j];
+        else if (p.emb_is_f64) v = static_cast<const double*>(p.emb)[(size_t)c * d + j];
+        else v = (double)static_cast<const float*>(p.emb)[(size_t)c * d + j];
+        p.En[(size_t)c * d + j] = v;
+        ss = fma(v, v, ss);
     }
-    for (int i = tid; i < n; i += 1024) { maxsim[i] = -INFINITY; alive[i] = 1; }
-    __threadfence_block();
-    __syncthreads();
+    if (p.metric == RAG_MMR_COSINE) {
+        ss = wave_sum_f64(ss);
+        double nrm = sqrt(ss);
+        if (nrm == 0.0) nrm = 1.0;
+        for (int j = lane; j < d; j += 64) p.En[(size_t)c * d + j] = p.En[(size_t)c * d + j] / nrm;
+    }
+    if (lane == 0) { st.maxsim[c] = -INFINITY; st.alive[c] = 1; }
+}
 
-    const int rounds = p.max_results < n ? p.max_results : n;
-    int last = -1;
-    for (int r = 0; r < rounds; ++r) {
-        // similarity of every remaining candidate to the row selected last round
+__device__ __forceinline__ bool mmr_better(double ob, int oi, double best, int bidx) {
+    // the reference starts from the first remaining candidate and moves on strict '>': the
+    // lowest index among equal maxima wins
+    return oi != 0x7FFFFFFF && (bidx == 0x7FFFFFFF || ob > best || (ob == best && oi < bidx));
+}
+
+// One selection round.  A single workgroup can only pull the candidate rows (n x d fp64, in L2)
+// through one CU's memory path -- 200 x 768 took 32 us per round that way -- so a round is a launch
+// of n / 8 small workgroups: each wave scores two candidates against the row selected last
+// (one fma chain per lane over j = lane, lane + 64, ..., then the xor-shuffle tree), the
+// workgroup posts its best marginal relevance, and the workgroup that arrives last reduces the
+// posts and records the selection.  Rounds are ordered by the stream.
+constexpr int MMR_WAVES = 4, MMR_PER_WAVE = 2, MMR_PER_WG = MMR_WAVES * MMR_PER_WAVE;
+__global__ __launch_bounds__(MMR_WAVES * 64) void mmr_round_kernel(MmrArgs p, MmrState st, int r) {
+    __shared__ double s_b[MMR_WAVES];
+    __shared__ int s_i[MMR_WAVES];
+    __shared__ int s_last_wg;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = p.n, d = p.d, G = gridDim.x;
+    const int last = r > 0 ? st.ctrl[1] : -1;
+    const int c0 = blockIdx.x * MMR_PER_WG + wave * MMR_PER_WAVE;
+    bool act[MMR_PER_WAVE];
+    const double* ec[MMR_PER_WAVE];
+    double acc[MMR_PER_WAVE];
+#pragma unroll
+    for (int u = 0; u < MMR_PER_WAVE; ++u) {
+        const int c = c0 + u;
+        act[u] = c < n && st.alive[c] != 0;
+        ec[u] = p.En + (size_t)(act[u] ? c : 0) * d;
+        acc[u] = 0.0;
+    }
+    double best = -INFINITY;
+    int bidx = 0x7FFFFFFF;
+    if (act[0] || act[1]) {
         if (last >= 0) {
             const double* es = p.En + (size_t)last * d;
-            for (int c = wave; c < n; c += 16) {
-                if (!alive[c]) continue;
-                const double* ec = p.En + (size_t)c * d;
-                double acc = 0.0;
-                if (p.metric == RAG_MMR_EUCLIDEAN) {
-                    for (int j = lane; j < d; j += 64) { const double df = ec[j] - es[j]; acc = fma(df, df, acc); }
-                    acc = wave_sum_f64(acc);
-                    acc = 1.0 / (1.0 + sqrt(acc));
-                } else {
-                    for (int j = lane; j < d; j += 64) acc = fma(ec[j], es[j], acc);
-                    acc = wave_sum_f64(acc);
-                }
-                if (lane == 0 && acc > maxsim[c]) maxsim[c] = acc;
-            }
-            __syncthreads();
-        }
-        // marginal relevance; first maximum wins
-        double best = -INFINITY;
-        int bidx = 0x7FFFFFFF;
-        for (int c = tid; c < n; c += 1024) {
-            if (!alive[c]) continue;
-            double m = 0.0;
-            if (last >= 0) { m = maxsim[c]; if (m < p.threshold) m = 0.0; }
-            const double v = __dsub_rn(__dmul_rn(p.lambda, p.rel[c]), __dmul_rn(1.0 - p.lambda, m));
-            // the reference starts from (best = -inf, first remaining) and moves on strict '>'
-            if (bidx == 0x7FFFFFFF) { bidx = c; best = (v > -INFINITY) ? v : -INFINITY; }
-            else if (v > best) { best = v; bidx = c; }
-        }
-        // reduce (best, lowest index among equals) over the wave, then over the waves
+            if (p.metric == RAG_MMR_EUCLIDEAN) {
+#pragma unroll 4
+                for (int j = lane; j < d; j += 64) {
+                    const double e = es[j];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const double ob = __shfl_xor(best, off, 64);
-            const int oi = __shfl_xor(bidx, off, 64);
-            if (oi != 0x7FFFFFFF && (bidx == 0x7FFFFFFF || ob > best || (ob == best && oi < bidx))) { best = ob; bidx = oi; }
-        }
-        if (lane == 0) { s_wbest[wave] = best; s_wbidx[wave] = bidx; }
-        __syncthreads();
-        if (tid == 0) {
-            double bb = s_wbest[0];
-            int bi = s_wbidx[0];
-            for (int w = 1; w < 16; ++w) {
-                const double ob = s_wbest[w];
-                const int oi = s_wbidx[w];
-                if (oi != 0x7FFFFFFF && (bi == 0x7FFFFFFF || ob > bb || (ob == bb && oi < bi))) { bb = ob; bi = oi; }
+                    for (int u = 0; u < MMR_PER_WAVE; ++u) { const double df = ec[u][j] - e; acc[u] = fma(df, df, acc[u]); }
+                }
+            } else {
+#pragma unroll 4
+                for (int j = lane; j < d; j += 64) {
+                    const double e = es[j];
+#pragma unroll
+                    for (int u = 0; u < MMR_PER_WAVE; ++u) acc[u] = fma(ec[u][j], e, acc[u]);
+                }
             }
-            s_best = bi;
-            if (bi != 0x7FFFFFFF) { alive[bi] = 0; p.out_idx[r] = bi; }
         }
-        __syncthreads();
-        last = s_best;
-        if (last == 0x7FFFFFFF) { if (tid == 0) *p.n_out = r; return; }
+#pragma unroll
+        for (int u = 0; u < MMR_PER_WAVE; ++u) {
+            const int c = c0 + u;
+            double m = 0.0;
+            if (last >= 0) {
+                double v = wave_sum_f64(acc[u]);
+                if (p.metric == RAG_MMR_EUCLIDEAN) v = 1.0 / (1.0 + sqrt(v));
+                if (act[u]) {
+                    m = st.maxsim[c];
+                    if (v > m) { m = v; if (lane == 0) st.maxsim[c] = v; }
+                    if (m < p.threshold) m = 0.0;
+                }
+            }
+            if (act[u]) {
+                const double v = __dsub_rn(__dmul_rn(p.lambda, p.rel[c]), __dmul_rn(1.0 - p.lambda, m));
+                if (bidx == 0x7FFFFFFF) { bidx = c; best = (v > -INFINITY) ? v : -INFINITY; }
+                else if (v > best) { best = v; bidx = c; }
+            }
+        }
     }
-    if (tid == 0) *p.n_out = rounds;
+    if (lane == 0) { s_b[wave] = best; s_i[wave] = bidx; }
+    __syncthreads();
+    if (tid == 0) {
+        double bb = s_b[0];
+        int bi = s_i[0];
+        for (int w = 1; w < MMR_WAVES; ++w)
+            if (mmr_better(s_b[w], s_i[w], bb, bi)) { bb = s_b[w]; bi = s_i[w]; }
+        st.wg_best[blockIdx.x] = bb;
+        st.wg_bidx[blockIdx.x] = bi;
+        __threadfence();                                   // the post is visible before the arrival
+        s_last_wg = (atomicAdd(&st.ctrl[0], 1) == G - 1);
+    }
+    __syncthreads();
+    if (!s_last_wg || wave != 0) return;
+    __threadfence();
+    best = -INFINITY;
+    bidx = 0x7FFFFFFF;
+    for (int g = lane; g < G; g += 64) {                   // increasing candidate index along g
+        const unsigned long long ob = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(st.wg_best + g),
+                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int oi = __hip_atomic_load(st.wg_bidx + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (mmr_better(__longlong_as_double((long long)ob), oi, best, bidx)) { best = __longlong_as_double((long long)ob); bidx = oi; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bidx, off, 64);
+        if (mmr_better(ob, oi, best, bidx)) { best = ob; bidx = oi; }
+    }
+    if (lane == 0) {
+        st.ctrl[0] = 0;
+        st.ctrl[1] = bidx;
+        if (bidx != 0x7FFFFFFF) {
+            st.alive[bidx] = 0;
+            p.out_idx[r] = bidx;
+            *p.n_out = r + 1;
+        }
+    }
 }
 
 static thread_local Workspace g_fuse_ws[64];
@@ -283,15 +334,25 @@ static int run_fuse(int mode, int64_t n, const double* a, const double* b, const
         RAG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fuse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(fuse_kernel, dim3(1), dim3(256), lds, s, p);
     RAG_HIP_CHECK(hipGetLastError());
-    int32_t m = 0;
-    RAG_HIP_CHECK(hipMemcpyAsync(&m, dnout, sizeof(int), hipMemcpyDeviceToHost, s));
-    RAG_HIP_CHECK(hipMemcpyAsync(out_score, ds, nb, hipMemcpyDeviceToHost, s));
+    // results come back in two copies: [order | n_out] (adjacent in the workspace) and the score arrays
+    // (adjacent too); the stream is synchronised once
+    const size_t ob = ((size_t)n * 4 + 255) & ~(size_t)255;
+    std::vector<int32_t> host_order(ob / 4 + 1);
+    RAG_HIP_CHECK(hipMemcpyAsync(host_order.data(), dorder, ob + sizeof(int), hipMemcpyDeviceToHost, s));
     if (mode == 1) {
-        RAG_HIP_CHECK(hipMemcpyAsync(out_a, dsa, nb, hipMemcpyDeviceToHost, s));
-        RAG_HIP_CHECK(hipMemcpyAsync(out_b, dsb, nb, hipMemcpyDeviceToHost, s));
+        std::vector<double> host_scores(3 * nbp / sizeof(double));
+        RAG_HIP_CHECK(hipMemcpyAsync(host_scores.data(), ds, 3 * nbp, hipMemcpyDeviceToHost, s));
+        RAG_HIP_CHECK(hipStreamSynchronize(s));
+        memcpy(out_score, host_scores.data(), nb);
+        memcpy(out_a, host_scores.data() + nbp / sizeof(double), nb);
+        memcpy(out_b, host_scores.data() + 2 * nbp / sizeof(double), nb);
+    } else {
+        RAG_HIP_CHECK(hipMemcpyAsync(out_score, ds, nb, hipMemcpyDeviceToHost, s));
+        RAG_HIP_CHECK(hipStreamSynchronize(s));
     }
-    RAG_HIP_CHECK(hipStreamSynchronize(s));
-    if (m > 0) RAG_HIP_CHECK(hipMemcpy(order, dorder, (size_t)m * sizeof(int), hipMemcpyDeviceToHost));
+    const int32_t m = host_order[ob / 4];
+    if (m < 0 || (int64_t)m > n) return fail(RAG_ERR_HIP, "fusion kernel returned a bad count");
+    if (m > 0) memcpy(order, host_order.data(), (size_t)m * sizeof(int32_t));
     *n_out = m;
     return RAG_OK;
 }
@@ -317,7 +378,10 @@ static int run_mmr(int device, int64_t n, int d, const void* emb, int emb_is_f64
     const size_t enb = ((size_t)n * d * 8 + 255) & ~(size_t)255;
     const size_t rb = ((size_t)n * 8 + 255) & ~(size_t)255;
     const size_t ob = ((size_t)n * 4 + 255) & ~(size_t)255;
-    if (int rc = ws.ensure(eb + enb + rb + ob + 256)) return rc;
+    const int G = (int)((n + MMR_PER_WG - 1) / MMR_PER_WG);
+    const size_t gb = ((size_t)G * 8 + 255) & ~(size_t)255;
+    // [rows or embeddings | En | rel | out_idx | n_out | maxsim | alive | wg_best | wg_bidx | ctrl]
+    if (int rc = ws.ensure(eb + enb + rb + ob + 256 + rb + ob + 2 * gb + 256)) return rc;
     char* base = static_cast<char*>(ws.ptr);
     hipStream_t s = nullptr;
     MmrArgs p;
@@ -334,18 +398,31 @@ static int run_mmr(int device, int64_t n, int d, const void* emb, int emb_is_f64
     double* drel = reinterpret_cast<double*>(base + eb + enb);
     int* dout = reinterpret_cast<int*>(base + eb + enb + rb);
     int* dn = reinterpret_cast<int*>(base + eb + enb + rb + ob);
+    char* sbase = base + eb + enb + rb + ob + 256;
+    MmrState st;
+    st.maxsim = reinterpret_cast<double*>(sbase);
+    st.alive = reinterpret_cast<int*>(sbase + rb);
+    st.wg_best = reinterpret_cast<double*>(sbase + rb + ob);
+    st.wg_bidx = reinterpret_cast<int*>(sbase + rb + ob + gb);
+    st.ctrl = reinterpret_cast<int*>(sbase + rb + ob + 2 * gb);
     RAG_HIP_CHECK(hipMemcpyAsync(drel, rel, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    RAG_HIP_CHECK(hipMemsetAsync(dn, 0, 256, s));
+    RAG_HIP_CHECK(hipMemsetAsync(st.ctrl, 0, 256, s));
     p.rel = drel; p.lambda = lambda; p.threshold = thr; p.metric = metric; p.n = (int)n; p.d = d;
     p.max_results = max_results; p.out_idx = dout; p.n_out = dn;
-    const size_t lds = 256 + (size_t)n * (8 + 4) + 16;
-    if (lds > 48 * 1024)
-        RAG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mmr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(mmr_kernel, dim3(1), dim3(1024), lds, s, p);
+    hipLaunchKernelGGL(mmr_prepare_kernel, dim3((unsigned)n), dim3(64), 0, s, p, st);
     RAG_HIP_CHECK(hipGetLastError());
-    int32_t m = 0;
-    RAG_HIP_CHECK(hipMemcpyAsync(&m, dn, sizeof(int), hipMemcpyDeviceToHost, s));
+    const int rounds = max_results < (int)n ? max_results : (int)n;
+    for (int r = 0; r < rounds; ++r)
+        hipLaunchKernelGGL(mmr_round_kernel, dim3((unsigned)G), dim3(MMR_WAVES * 64), 0, s, p, st, r);
+    RAG_HIP_CHECK(hipGetLastError());
+    // [out_idx | n_out] are adjacent in the workspace: one copy, one synchronisation
+    std::vector<int32_t> host_out(ob / 4 + 1);
+    RAG_HIP_CHECK(hipMemcpyAsync(host_out.data(), dout, ob + sizeof(int), hipMemcpyDeviceToHost, s));
     RAG_HIP_CHECK(hipStreamSynchronize(s));
-    if (m > 0) RAG_HIP_CHECK(hipMemcpy(out_idx, dout, (size_t)m * sizeof(int), hipMemcpyDeviceToHost));
+    const int32_t m = host_out[ob / 4];
+    if (m < 0 || (int64_t)m > n) return fail(RAG_ERR_HIP, "MMR kernel returned a bad count");
+    if (m > 0) memcpy(out_idx, host_out.data(), (size_t)m * sizeof(int32_t));
     *n_out = m;
     return RAG_OK;
 }
