@@ -87,7 +87,7 @@ __host__ __device__ constexpr int gemm_trig_max(int RT, int QT) { return QT >= 1
 // on unstructured data), so it triggers later.
 __host__ __device__ constexpr int gemm_trig(int RT, int QT, int k, bool b16 = false) {
     return QT >= 128 ? (b16 ? (k <= 16 ? 128 : RT) : (k <= 16 ? 32 : (k <= 32 ? 64 : 128)))
-                     : (k <= 32 ? 64 : 128);
+                     : (b16 ? 128 : (k <= 32 ? 64 : 128));
 }
 __host__ __device__ constexpr int gemm_capq(int RT, int QT) { return gemm_trig_max(RT, QT) + RT; }
 
@@ -165,7 +165,9 @@ __device__ __forceinline__ void push_candidate(const GemmArgs& a, u64* cand, int
 
 // bf16 pass: keys a (query, row range) may hand to the re-scoring step -- 128, or 64 when one query
 // block is split over more than 128 row ranges (each range then sees few rows and keeps few)
-static int pref_outc(int S) { return S <= 128 ? 128 : 64; }
+// (32, or 64 for k > 10, in the narrow 256 x 32 shape, whose 512 ranges of a query see 1/512 of the corpus each and are
+// cut at the best threshold any range has published)
+static int pref_outc(int S, int QT = 256, int k = 10) { return QT == 32 ? (k <= 10 ? 32 : 64) : (S <= 128 ? 128 : 64); }
 
 // number of leading keys of a descending list whose score is above `thr` (wave-wide, n <= 512)
 __device__ __forceinline__ int count_above(const u64* sorted, int n, float thr, int lane) {
@@ -556,8 +558,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
             u64* out = TASKS ? a.part + (size_t)a.pair_slot[p0 + ql] * k
                              : a.part + ((size_t)(q0 + ql) * a.S + sp) * a.outc;
             if constexpr (B16) {
+                // kept: above the range's own k-th best minus the margin and not below what any
+                // range has published (its k-th best minus the margin)
                 int keep = c;
-                if (c >= k) keep = count_above(scratch, c, key_score(scratch[k - 1]) - s_margin[ql], lane);
+                float cut = c >= k ? key_score(scratch[k - 1]) - s_margin[ql] : -INFINITY;
+                if (a.gthr) {
+                    const unsigned int o = __hip_atomic_load(&a.gthr[q0 + ql], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (o != 0u) cut = fmaxf(cut, ordered_f32(o));
+                }
+                if (cut > -INFINITY) keep = count_above(scratch, c, cut, lane);
                 if (keep > a.outc) {
                     if (lane == 0) *a.overflow = 1;
                     keep = a.outc;
@@ -579,6 +588,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
 // select the k best exact scores.
 struct RescoreArgs {
     const u64* part;        // [nq][S * outc]
+    int outc;               // keys per row range (a descending run)
     int per_query;          // S * outc
     const float* X;         // fp32 rows
     const float* Q;         // fp32 padded queries
@@ -612,11 +622,24 @@ __global__ __launch_bounds__(256) void rescore_select_kernel(RescoreArgs r) {
     const long long q = blockIdx.x;
     const int k = r.fin.k;
     const u64* in = r.part + (size_t)q * r.per_query;
+    // every row range handed over a descending run of `outc` keys: the k-th largest run head is at
+    // most the k-th best approximate score, so nothing below (that head - margin) can matter --
+    // with many short ranges most of what they kept falls below it and never enters the buffer
+    u64 floor_key = KEY_EMPTY;
+    const int runs = r.outc > 0 ? (int)(r.per_query / r.outc) : 0;
+    if (runs >= k && runs <= RESC_CAP) {
+        const int h2 = pow2_ceil(runs);
+        for (int i = tid; i < h2; i += 256) buf[i] = i < runs ? in[(size_t)i * r.outc] : KEY_EMPTY;
+        bitonic_sort_desc_lds(buf, h2, tid, 256, SyncBlock());
+        const u64 hk = buf[k - 1];
+        __syncthreads();
+        if (hk != KEY_EMPTY) floor_key = make_key(key_score(hk) - r.margin[q], 0xFFFFFFFFu);   // lowest key of that score
+    }
     if (tid == 0) s_n = 0;
     __syncthreads();
     for (int i = tid; i < r.per_query; i += 256) {
         const u64 key = in[i];
-        if (key != KEY_EMPTY) {
+        if (key != KEY_EMPTY && key >= floor_key) {
             const int pos = atomicAdd(&s_n, 1);
             if (pos < RESC_CAP) buf[pos] = key;
         }
@@ -759,10 +782,15 @@ static GemmPlan gemm_plan(const rag_index* h, long long nq, int k) {
     p.part_bytes = ((size_t)nq * p.S * k * sizeof(u64) + 255) & ~(size_t)255;
     p.gthr_bytes = ((size_t)nq * sizeof(unsigned int) + 255) & ~(size_t)255;
     // the bf16 first pass pays off where the batch is MFMA-bound: the 256 x 256 shape
-    p.pref = h->prefilter && p.QT == 256 && (h->ld % (2 * GK)) == 0 && (long long)p.S * pref_outc(p.S) <= 16384;
+    // ... and, as one pass over half the bytes, the narrow shape of 5..32 queries (k <= 16: a row range hands over
+    // at most 64 keys, and at k = 20 the keys within the margin of a range's k-th best outgrow that now and then,
+    // which sends the batch through the fp32 kernel as well)
+    static const int narrow16 = env_int_g("RAG_GEMM_NARROW_BF16", 1);
+    const bool shape_ok = p.QT == 256 || (p.QT == 32 && narrow16 && k <= 16 && h->n >= 262144 && p.S > 1);
+    p.pref = h->prefilter && shape_ok && (h->ld % (2 * GK)) == 0 && (long long)p.S * pref_outc(p.S, p.QT, k) <= 32768;
     p.qb_bytes = p.pref ? (((size_t)nq * h->ld * 2 + 255) & ~(size_t)255) : 0;
     p.margin_bytes = p.pref ? (((size_t)nq * sizeof(float) + 255) & ~(size_t)255) : 0;
-    p.part16_bytes = p.pref ? (size_t)nq * p.S * pref_outc(p.S) * sizeof(u64) : 0;
+    p.part16_bytes = p.pref ? (size_t)nq * p.S * pref_outc(p.S, p.QT, k) * sizeof(u64) : 0;
     return p;
 }
 
@@ -872,14 +900,16 @@ int gemm_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float
         b.part = part16;
         b.margin = margin;
         b.overflow = flag;
-        b.outc = pref_outc(p.S);
-        b.trig = gemm_trig(256, 256, k, true);
+        b.outc = pref_outc(p.S, p.QT, k);
+        b.trig = gemm_trig(256, p.QT, k, true);
         if (int rc = profile_begin(h, s)) return rc;
-        if (int rc = launch_gemm<256, 256, 8, true>(b, grid, h->device, s)) return rc;
+        if (p.QT == 32) { if (int rc = launch_gemm<256, 32, 4, true>(b, grid, h->device, s)) return rc; }
+        else if (int rc = launch_gemm<256, 256, 8, true>(b, grid, h->device, s)) return rc;
         if (int rc = profile_end(h, s)) return rc;
         RescoreArgs r = {};
         r.part = part16;
-        r.per_query = p.S * pref_outc(p.S);
+        r.per_query = p.S * pref_outc(p.S, p.QT, k);
+        r.outc = pref_outc(p.S, p.QT, k);
         r.X = h->X;
         r.Q = qbuf;
         r.margin = margin;
@@ -899,7 +929,8 @@ int gemm_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float
         RAG_HIP_CHECK(hipGetLastError());
         a.run_if = flag;
         m.run_if = flag;
-        if (int rc = launch_gemm<256, 256, 8>(a, grid, h->device, s)) return rc;
+        if (p.QT == 32) { if (int rc = launch_gemm<256, 32, 4>(a, grid, h->device, s)) return rc; }
+        else if (int rc = launch_gemm<256, 256, 8>(a, grid, h->device, s)) return rc;
         RAG_HIP_CHECK(launch_merge_keys(m, nq, s));
         h->last_path = "gemm-bf16";
         return RAG_OK;
