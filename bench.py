@@ -251,12 +251,21 @@ def main():
         mid = batch_leg(min(args.mid_batch, args.big_batch), min(args.steps, 20))
     # opt-in mode, reported beside the fp32 numbers and never as `value`: bf16 first pass on the
     # matrix cores + fp32 re-scoring of the rows within the error margin (same answers)
-    pre = pre1 = None
+    pre = pre1 = pre_mid = None
     if not args.no_big and not args.no_prefilter and args.big_batch >= 1024:
         index.set_prefilter(True)
         pre = batch_leg(args.big_batch, args.big_steps or min(args.steps, 5), BF16_MFMA_PEAK_TFLOPS)
         pre["roofline"]["traffic"] = None
         pre["dtype"] = "bf16 first pass (fp32 accumulate) + f32 re-score of the kept rows"
+        if mid is not None:      # the serving-sized batch: one pass over the bf16 copy in the narrow shape
+            pre_mid = batch_leg(mid["batch"], min(args.steps, 20), BF16_MFMA_PEAK_TFLOPS)
+            pre_mid["dtype"] = pre["dtype"]
+            r = pre_mid["roofline"]                 # one pass over the bf16 rows (half the bytes): HBM-bound
+            gb = r["corpus_GBps"] / 2
+            pre_mid["roofline"] = {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": gb / HBM_PEAK_GBS, "traffic": None,
+                                   "kernel_ms_per_step": r["kernel_ms_per_step"], "launches": r["launches"],
+                                   "algorithmic_bytes_per_launch": (hi - lo) * args.dim * 2}
         # batch 1: scan of the bf16 copy (half the bytes), fp32 re-score of the 64 kept rows, acceptance test
         index.profile_read(reset=True)
         for i in range(3):
@@ -300,6 +309,8 @@ def main():
             out["batch_%d" % mid["batch"]] = mid
         if pre is not None:
             out["batch_%d_bf16_first_pass" % args.big_batch] = pre
+        if pre_mid is not None:
+            out["batch_%d_bf16_first_pass" % pre_mid["batch"]] = pre_mid
         if pre1 is not None:
             out["batch_1_bf16_first_pass"] = pre1
         if cpu is not None:
