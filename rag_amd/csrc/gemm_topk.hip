@@ -165,9 +165,9 @@ __device__ __forceinline__ void push_candidate(const GemmArgs& a, u64* cand, int
 
 // bf16 pass: keys a (query, row range) may hand to the re-scoring step -- 128, or 64 when one query
 // block is split over more than 128 row ranges (each range then sees few rows and keeps few)
-// (32, or 64 for k > 10, in the narrow 256 x 32 shape, whose 512 ranges of a query see 1/512 of the corpus each and are
+// (32, 64 for k > 10, 128 for k > 16 in the narrow 256 x 32 shape, whose 512 ranges of a query see 1/512 of the corpus each and are
 // cut at the best threshold any range has published)
-static int pref_outc(int S, int QT = 256, int k = 10) { return QT == 32 ? (k <= 10 ? 32 : 64) : (S <= 128 ? 128 : 64); }
+static int pref_outc(int S, int QT = 256, int k = 10) { return QT == 32 ? (k <= 10 ? 32 : k <= 16 ? 64 : 128) : (S <= 128 ? 128 : 64); }
 
 // number of leading keys of a descending list whose score is above `thr` (wave-wide, n <= 512)
 __device__ __forceinline__ int count_above(const u64* sorted, int n, float thr, int lane) {
@@ -782,12 +782,13 @@ static GemmPlan gemm_plan(const rag_index* h, long long nq, int k) {
     p.part_bytes = ((size_t)nq * p.S * k * sizeof(u64) + 255) & ~(size_t)255;
     p.gthr_bytes = ((size_t)nq * sizeof(unsigned int) + 255) & ~(size_t)255;
     // the bf16 first pass pays off where the batch is MFMA-bound: the 256 x 256 shape
-    // ... and, as one pass over half the bytes, the narrow shape of 5..32 queries (k <= 16: a row range hands over
-    // at most 64 keys, and at k = 20 the keys within the margin of a range's k-th best outgrow that now and then,
-    // which sends the batch through the fp32 kernel as well)
+    // ... and, as one pass over half the bytes, the narrow shape of 5..32 queries (k <= 32: the keys within the
+    // margin of a range's k-th best -- about 2k on unstructured data -- have to fit the 128 keys a range hands
+    // over and the 128-key trigger of its candidate buffers, or the batch goes through the fp32 kernel as well)
     static const int narrow16 = env_int_g("RAG_GEMM_NARROW_BF16", 1);
-    const bool shape_ok = p.QT == 256 || (p.QT == 32 && narrow16 && k <= 16 && h->n >= 262144 && p.S > 1);
-    p.pref = h->prefilter && shape_ok && (h->ld % (2 * GK)) == 0 && (long long)p.S * pref_outc(p.S, p.QT, k) <= 32768;
+    static const int narrow_kmax = env_int_g("RAG_GEMM_NARROW_BF16_KMAX", 32);       // measurement only
+    const bool shape_ok = p.QT == 256 || (p.QT == 32 && narrow16 && k <= narrow_kmax && h->n >= 262144 && p.S > 1);
+    p.pref = h->prefilter && shape_ok && (h->ld % (2 * GK)) == 0 && (long long)p.S * pref_outc(p.S, p.QT, k) <= 65536;
     p.qb_bytes = p.pref ? (((size_t)nq * h->ld * 2 + 255) & ~(size_t)255) : 0;
     p.margin_bytes = p.pref ? (((size_t)nq * sizeof(float) + 255) & ~(size_t)255) : 0;
     p.part16_bytes = p.pref ? (size_t)nq * p.S * pref_outc(p.S, p.QT, k) * sizeof(u64) : 0;
