@@ -733,9 +733,21 @@ __global__ void queries_to_bf16_kernel(const float* Q, int ld, const int* maxnor
 }
 
 
+// bf16 first pass in the narrow 256 x 32 shape: one pass over half the bytes for up to 32 queries (k <= 32: the
+// keys within the margin of a range's k-th best -- about 2k on unstructured data -- have to fit the 128 keys a
+// range hands over and the 128-key trigger of its candidate buffers, or the batch goes through the fp32 kernel
+// as well); the corpus has to give the single query block its row ranges
+static bool narrow_bf16_ok(const rag_index* h, int k) {
+    static const int narrow16 = env_int_g("RAG_GEMM_NARROW_BF16", 1);
+    static const int narrow_kmax = env_int_g("RAG_GEMM_NARROW_BF16_KMAX", 32);       // measurement only
+    return h->prefilter && narrow16 && k <= narrow_kmax && h->n >= 262144 && (h->ld % (2 * GK)) == 0;
+}
+
+// from 5 queries; with the bf16 first pass in the narrow shape from 2 (half a corpus pass instead of a whole one)
 bool gemm_topk_supported(const rag_index* h, long long nq, int k) {
     static const int min_nq = env_int_g("RAG_GEMM_MIN_NQ", 5);
-    return h->kind == RAG_KIND_FLAT && nq >= min_nq && k <= GEMM_MAX_K && (h->ld % GK) == 0 && h->n >= 1;
+    if (!(h->kind == RAG_KIND_FLAT && k <= GEMM_MAX_K && (h->ld % GK) == 0 && h->n >= 1)) return false;
+    return nq >= min_nq || (nq >= 2 && narrow_bf16_ok(h, k));
 }
 
 struct GemmPlan {
@@ -782,12 +794,8 @@ static GemmPlan gemm_plan(const rag_index* h, long long nq, int k) {
     p.part_bytes = ((size_t)nq * p.S * k * sizeof(u64) + 255) & ~(size_t)255;
     p.gthr_bytes = ((size_t)nq * sizeof(unsigned int) + 255) & ~(size_t)255;
     // the bf16 first pass pays off where the batch is MFMA-bound: the 256 x 256 shape
-    // ... and, as one pass over half the bytes, the narrow shape of 5..32 queries (k <= 32: the keys within the
-    // margin of a range's k-th best -- about 2k on unstructured data -- have to fit the 128 keys a range hands
-    // over and the 128-key trigger of its candidate buffers, or the batch goes through the fp32 kernel as well)
-    static const int narrow16 = env_int_g("RAG_GEMM_NARROW_BF16", 1);
-    static const int narrow_kmax = env_int_g("RAG_GEMM_NARROW_BF16_KMAX", 32);       // measurement only
-    const bool shape_ok = p.QT == 256 || (p.QT == 32 && narrow16 && k <= narrow_kmax && h->n >= 262144 && p.S > 1);
+    // ... and, as one pass over half the bytes, the narrow shape of up to 32 queries
+    const bool shape_ok = p.QT == 256 || (p.QT == 32 && narrow_bf16_ok(h, k) && p.S > 1);
     p.pref = h->prefilter && shape_ok && (h->ld % (2 * GK)) == 0 && (long long)p.S * pref_outc(p.S, p.QT, k) <= 65536;
     p.qb_bytes = p.pref ? (((size_t)nq * h->ld * 2 + 255) & ~(size_t)255) : 0;
     p.margin_bytes = p.pref ? (((size_t)nq * sizeof(float) + 255) & ~(size_t)255) : 0;

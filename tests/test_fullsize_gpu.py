@@ -132,6 +132,11 @@ def test_bf16_first_pass_returns_the_fp32_answer(corpus):
         assert idx.last_path == "gemm-bf16"
         assert torch.equal(I16, I32)
         assert np.allclose(D16.cpu().numpy(), D32.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        for nq in (2, 4, 17, 32):          # one pass over the bf16 rows in the narrow shape
+            Dn, In = idx.search(Qbig[:nq], K)
+            assert idx.last_path == "gemm-bf16"
+            assert torch.equal(In, I32[:nq])
+            assert np.allclose(Dn.cpu().numpy(), D32[:nq].cpu().numpy(), rtol=1e-5, atol=1e-6)
         for qi, (Ds, Is) in singles.items():
             Dp, Ip = idx.search(Qbig[qi:qi + 1], K)
             assert idx.last_path == "scan-bf16"
