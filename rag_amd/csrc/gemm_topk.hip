@@ -771,7 +771,8 @@ static GemmPlan gemm_plan(const rag_index* h, long long nq, int k) {
     const int big_from = (h->prefilter && h->n >= 262144) ? std::min(big_min_nq, 33) : big_min_nq;
     // below that, the 256 x 256 shape still wins 2-3 % over 128 x 128 wherever it pads the batch no further
     // (129..256, 385..512, ... queries: 256 queries 30.6 -> 30.0 ms, 512: 59.6 -> 58.3, 768: 89.3 -> 86.9)
-    const bool same_pad = nq > 128 && (nq + 255) / 256 * 256 == (nq + 127) / 128 * 128;
+    // (on a corpus of 1M+ rows: a shorter one cannot give the fewer, larger workgroups 8 tiles each on every CU)
+    const bool same_pad = nq > 128 && h->n >= (1 << 20) && (nq + 255) / 256 * 256 == (nq + 127) / 128 * 128;
     p.QT = force_qt ? force_qt : ((nq >= big_from || same_pad) ? 256 : nq <= 32 ? 32 : nq <= 64 ? 64 : 128);
     p.RT = (p.QT == 32 || p.QT == 256) ? 256 : 128;
     p.NW = p.QT == 256 ? 8 : 4;
