@@ -164,10 +164,11 @@ __device__ __forceinline__ void push_candidate(const GemmArgs& a, u64* cand, int
 }
 
 // bf16 pass: keys a (query, row range) may hand to the re-scoring step -- 128, or 64 when one query
-// block is split over more than 128 row ranges (each range then sees few rows and keeps few)
+// block is split over more than 128 row ranges (each range then sees few rows and keeps few); for k > 16
+// twice that (the keys within the margin of the k-th best number about 2k to 3k on unstructured data)
 // (32, 64 for k > 10, 128 for k > 16 in the narrow 256 x 32 shape, whose 512 ranges of a query see 1/512 of the corpus each and are
 // cut at the best threshold any range has published)
-static int pref_outc(int S, int QT = 256, int k = 10) { return QT == 32 ? (k <= 10 ? 32 : k <= 16 ? 64 : 128) : (S <= 128 ? 128 : 64); }
+static int pref_outc(int S, int QT = 256, int k = 10) { return QT <= 64 ? (k <= 10 ? 32 : k <= 16 ? 64 : 128) : (k > 16 ? (S <= 64 ? 256 : 128) : (S <= 128 ? 128 : 64)); }
 
 // number of leading keys of a descending list whose score is above `thr` (wave-wide, n <= 512)
 __device__ __forceinline__ int count_above(const u64* sorted, int n, float thr, int lane) {
@@ -773,7 +774,11 @@ static GemmPlan gemm_plan(const rag_index* h, long long nq, int k) {
     // (129..256, 385..512, ... queries: 256 queries 30.6 -> 30.0 ms, 512: 59.6 -> 58.3, 768: 89.3 -> 86.9)
     // (on a corpus of 1M+ rows: a shorter one cannot give the fewer, larger workgroups 8 tiles each on every CU)
     const bool same_pad = nq > 128 && h->n >= (1 << 20) && (nq + 255) / 256 * 256 == (nq + 127) / 128 * 128;
-    p.QT = force_qt ? force_qt : ((nq >= big_from || same_pad) ? 256 : nq <= 32 ? 32 : nq <= 64 ? 64 : 128);
+    // 33..64 queries with the bf16 first pass: the 128 x 64 shape, whose query tile is a third of a K step's
+    // loads instead of half of them
+    static const int mid16 = env_int_g("RAG_GEMM_MID_BF16", 1);
+    const bool mid_b16 = mid16 && nq > 32 && nq <= 64 && narrow_bf16_ok(h, k);
+    p.QT = force_qt ? force_qt : mid_b16 ? 64 : ((nq >= big_from || same_pad) ? 256 : nq <= 32 ? 32 : nq <= 64 ? 64 : 128);
     p.RT = (p.QT == 32 || p.QT == 256) ? 256 : 128;
     p.NW = p.QT == 256 ? 8 : 4;
     const int target_wgs = target_wgs_env > 0 ? target_wgs_env : (p.NW == 8 ? 256 : 512);
@@ -799,8 +804,10 @@ static GemmPlan gemm_plan(const rag_index* h, long long nq, int k) {
     p.gthr_bytes = ((size_t)nq * sizeof(unsigned int) + 255) & ~(size_t)255;
     // the bf16 first pass pays off where the batch is MFMA-bound: the 256 x 256 shape
     // ... and, as one pass over half the bytes, the narrow shape of up to 32 queries
-    const bool shape_ok = p.QT == 256 || (p.QT == 32 && narrow_bf16_ok(h, k) && p.S > 1);
-    p.pref = h->prefilter && shape_ok && (h->ld % (2 * GK)) == 0 && (long long)p.S * pref_outc(p.S, p.QT, k) <= 65536;
+    const bool shape_ok = p.QT == 256 || ((p.QT == 32 || p.QT == 64) && narrow_bf16_ok(h, k) && p.S > 1);
+    // k <= 32: above, the keys within the margin of the k-th best outgrow the buffers somewhere in nearly every
+    // batch, and one overflow sends the whole batch through the fp32 kernel as well
+    p.pref = h->prefilter && shape_ok && k <= 32 && (h->ld % (2 * GK)) == 0 && (long long)p.S * pref_outc(p.S, p.QT, k) <= 65536;
     p.qb_bytes = p.pref ? (((size_t)nq * h->ld * 2 + 255) & ~(size_t)255) : 0;
     p.margin_bytes = p.pref ? (((size_t)nq * sizeof(float) + 255) & ~(size_t)255) : 0;
     p.part16_bytes = p.pref ? (size_t)nq * p.S * pref_outc(p.S, p.QT, k) * sizeof(u64) : 0;
@@ -917,6 +924,7 @@ int gemm_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float
         b.trig = gemm_trig(256, p.QT, k, true);
         if (int rc = profile_begin(h, s)) return rc;
         if (p.QT == 32) { if (int rc = launch_gemm<256, 32, 4, true>(b, grid, h->device, s)) return rc; }
+        else if (p.QT == 64) { if (int rc = launch_gemm<128, 64, 4, true>(b, grid, h->device, s)) return rc; }
         else if (int rc = launch_gemm<256, 256, 8, true>(b, grid, h->device, s)) return rc;
         if (int rc = profile_end(h, s)) return rc;
         RescoreArgs r = {};
@@ -943,6 +951,7 @@ int gemm_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float
         a.run_if = flag;
         m.run_if = flag;
         if (p.QT == 32) { if (int rc = launch_gemm<256, 32, 4>(a, grid, h->device, s)) return rc; }
+        else if (p.QT == 64) { if (int rc = launch_gemm<128, 64, 4>(a, grid, h->device, s)) return rc; }
         else if (int rc = launch_gemm<256, 256, 8>(a, grid, h->device, s)) return rc;
         RAG_HIP_CHECK(launch_merge_keys(m, nq, s));
         h->last_path = "gemm-bf16";

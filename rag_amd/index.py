@@ -106,7 +106,7 @@ class DeviceIndex:
         check(lib.rag_index_set_id_base(self._h, int(base)))
 
     def set_prefilter(self, enabled: bool) -> None:
-        """bf16 first pass for single queries (k <= 256), batches of 2..32 queries (k <= 32) and of 33+ queries (results are re-scored in fp32 and equal
+        """bf16 first pass for single queries (k <= 256) and batches (k <= 32) (results are re-scored in fp32 and equal
         those of the fp32 path); keeps a bf16 copy of the rows on the device."""
         check(lib.rag_index_set_prefilter(self._h, 1 if enabled else 0))
 

@@ -26,7 +26,8 @@ def _check(D, I, X, Q, k, **kw):
 @pytest.mark.parametrize("n,d,nq,k", [(60_000, 768, 1024, 10), (30_000, 384, 1500, 64), (20_000, 1024, 2048, 1),
                                       (700, 128, 1100, 10), (50_000, 768, 600, 10), (540_000, 384, 130, 10), (600_000, 256, 300, 16), (524_288, 128, 40, 10),
                                       (600_000, 128, 32, 10), (530_000, 256, 9, 20), (530_000, 256, 9, 16), (540_000, 64, 20, 1), (530_000, 128, 17, 64), (530_000, 128, 12, 21), (530_000, 128, 32, 32), (530_000, 64, 31, 33),
-                                      (530_000, 128, 2, 10), (530_000, 256, 4, 20), (540_000, 64, 3, 32), (530_000, 128, 2, 33)])
+                                      (530_000, 128, 2, 10), (530_000, 256, 4, 20), (540_000, 64, 3, 32), (530_000, 128, 2, 33),
+                                      (530_000, 256, 64, 16), (530_000, 64, 50, 32), (40_000, 128, 1100, 32), (530_000, 64, 300, 20)])
 def test_prefilter_matches_oracle(n, d, nq, k):
     from rag_amd import DeviceIndex
     rng = np.random.default_rng(n + d + nq)
@@ -35,10 +36,10 @@ def test_prefilter_matches_oracle(n, d, nq, k):
     idx = DeviceIndex(d, metric="ip")
     idx.add(X[: n // 2])
     idx.set_prefilter(True)
-    def path(rows):          # the bf16 pass starts at 1024 queries; on a corpus of 262144+ rows at 33, and at 2..32 for k <= 32
+    def path(rows):          # the bf16 pass (k <= 32) starts at 1024 queries, on a corpus of 262144+ rows at 2
         if nq < 5 and not (rows >= 262144 and k <= 32):
             return "scan"
-        return "gemm-bf16" if nq >= 1024 or (rows >= 262144 and (nq >= 33 or k <= 32)) else "gemm"
+        return "gemm-bf16" if k <= 32 and (nq >= 1024 or rows >= 262144) else "gemm"
     D, I = idx.search(Q, k)
     assert idx.last_path == path(n // 2)
     _check(D, I, X[: n // 2], Q, k)
