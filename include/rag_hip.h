@@ -75,7 +75,7 @@ int rag_index_adopt_device(rag_index_t* h, int64_t n, float* x_dev);
  * multi-GPU corpus: base = first global row of the shard) */
 int rag_index_set_id_base(rag_index_t* h, int64_t base);
 /* Optional acceleration of large batches (vector_db/search_optimizer.py:276-323 batch_search,
- * from 33 queries, k <= 32, from 2 queries (from 1024 on a corpus under 262144 rows), dim % 64 == 0, FLAT): mode 1 keeps a bf16 copy of the rows, runs the
+ * k <= 32, from 2 queries on a corpus of 262144+ rows and from 1024 queries below, dim % 64 == 0, FLAT): mode 1 keeps a bf16 copy of the rows, runs the
  * contraction on bf16 matrix cores and keeps every row whose approximate score is within a
  * proven error margin of the k-th best; those rows are re-scored in fp32 and the k best are
  * returned, so ids and scores are those of the fp32 path.  A single query with k <= 256 scans the
