@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised parity run of the bf16 first pass in the narrow shape (2..32 queries, k <= 32, corpus of
+"""Randomised parity run of the bf16 first pass in the narrow shapes (2..64 queries, k <= 32, corpus of
 262144+ rows) against the CPU oracle: varying row norms, exact ties, near-duplicate clusters (many keys
 within the margin, which forces the fp32 fall-back), masks and min_score.  CASES=n, SEED=s."""
 import os
@@ -19,7 +19,7 @@ t0 = time.time()
 for case in range(int(os.environ.get("CASES", 60))):
     d = int(rng.choice([64, 128, 256]))
     n = int(rng.integers(262_144, 420_000))
-    nq = int(rng.integers(2, 33))
+    nq = int(rng.integers(2, 65))
     k = int(rng.choice([1, 2, 5, 10, 11, 16, 17, 20, 32]))
     X = rng.standard_normal((n, d)).astype(np.float32)
     X /= np.linalg.norm(X, axis=1, keepdims=True)
