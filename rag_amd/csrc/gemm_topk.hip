@@ -777,7 +777,8 @@ static GemmPlan gemm_plan(const rag_index* h, long long nq, int k) {
     // 33..64 queries with the bf16 first pass: the 128 x 64 shape, whose query tile is a third of a K step's
     // loads instead of half of them
     static const int mid16 = env_int_g("RAG_GEMM_MID_BF16", 1);
-    const bool mid_b16 = mid16 && nq > 32 && nq <= 64 && narrow_bf16_ok(h, k);
+    static const int mid16_maxq = env_int_g("RAG_GEMM_MID_BF16_MAXQ", 64);        // measurement only
+    const bool mid_b16 = mid16 && nq > 32 && nq <= mid16_maxq && narrow_bf16_ok(h, k);
     p.QT = force_qt ? force_qt : mid_b16 ? 64 : ((nq >= big_from || same_pad) ? 256 : nq <= 32 ? 32 : nq <= 64 ? 64 : 128);
     p.RT = (p.QT == 32 || p.QT == 256) ? 256 : 128;
     p.NW = p.QT == 256 ? 8 : 4;
