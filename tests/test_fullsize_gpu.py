@@ -126,8 +126,21 @@ def test_bf16_first_pass_returns_the_fp32_answer(corpus):
     D32, I32 = idx.search(Qbig, K)
     assert idx.last_path == "gemm"
     singles = {qi: idx.search(Qbig[qi:qi + 1], K) for qi in (0, 3, 64, 500, 1099)}
+    wide = {(nq, k): idx.search(Qbig[:nq], k) for nq, k in ((32, 32), (48, 20), (64, 32), (300, 32), (1100, 32))}
     idx.set_prefilter(True)
     try:
+        for (nq, k), (Dw, Iw) in wide.items():      # k above 16: wider hand-over of the row ranges
+            Dn, In = idx.search(Qbig[:nq], k)
+            assert idx.last_path == "gemm-bf16"
+            # the two paths sum in different orders: ids may swap where scores tie within the tolerance
+            from oracle import flat
+            bad = flat.compare_topk(Dn.cpu().numpy(), In.cpu().numpy(), Dw.cpu().numpy(), Iw.cpu().numpy(), rtol=1e-5, atol=1e-6)
+            assert bad == [], ((nq, k), bad[:3])
+        for nq in (40, 64):                 # the 128 x 64 shape
+            Dn, In = idx.search(Qbig[:nq], K)
+            assert idx.last_path == "gemm-bf16"
+            assert torch.equal(In, I32[:nq])
+            assert np.allclose(Dn.cpu().numpy(), D32[:nq].cpu().numpy(), rtol=1e-5, atol=1e-6)
         D16, I16 = idx.search(Qbig, K)
         assert idx.last_path == "gemm-bf16"
         assert torch.equal(I16, I32)
