@@ -33,7 +33,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA peak
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -47,8 +47,37 @@ def parse():
     ap.add_argument("--no-prefilter", action="store_true", help="skip the opt-in bf16-first-pass leg")
     ap.add_argument("--mid-batch", type=int, default=32, help="a serving-sized batch reported beside the two headline ones (0: skip)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-side", action="store_true", help="skip the legs on the other configurations (small corpus, pipeline, IVF)")
     ap.add_argument("--cpu-rows", type=int, default=1_000_000)
-    return ap.parse_args()
+    ap.add_argument("--stub-cpu", action="store_true",
+                    help="rehearsal of the launch / exchange path without a GPU: gloo, a torch CPU scan stands in for the "
+                         "HIP search (never a measurement; the JSON line says data = stub-cpu)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL) is the product path; gloo only rehearses the N-rank path where RCCL cannot run")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal: ranks beyond the visible GPUs share them (with --dist-backend gloo)")
+    return ap.parse_args(argv)
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes through
+    torch.distributed.run (one per GPU) and hand back their exit status.  Runs before this
+    process has imported torch or touched the GPU; the parent only waits."""
+    import subprocess
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1" if args.stub_cpu else env.get("OMP_NUM_THREADS", "16"))
+    return subprocess.run(cmd, env=env).returncode
 
 
 def measured_traffic(kernel, rows, dim, world):
@@ -91,25 +120,133 @@ def make_queries(torch, nq, dim, device):
 
 
 def timed_steps(torch, dist, world, step, nwarm, nsteps, device):
+    """nwarm untimed steps, then exactly nsteps timed ones between barrier + device
+    synchronisation on both sides; the time returned is the maximum over the ranks."""
+    def sync():
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+
     for i in range(nwarm):
         step(i)
-    torch.cuda.synchronize(device)
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize(device)
+    sync()
     t0 = time.perf_counter()
     for i in range(nsteps):
         step(nwarm + i)
-    torch.cuda.synchronize(device)
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize(device)
+    sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        on_host = dist.get_backend() == "gloo"
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if on_host else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
+
+
+def rendezvous(args):
+    """(world, rank, local_rank) from the launcher's environment.  The world the launcher
+    made must be the one --gpus asked for: a mismatch ends the run with status 2."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"error: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+        sys.exit(2)
+    return world, rank, local
+
+
+def check_world(dist, world):
+    """The process group must have the size the launcher announced (RCCL / gloo saw every rank)."""
+    seen = dist.get_world_size() if world > 1 else 1
+    if seen != world:
+        print(f"error: process group has {seen} ranks, expected {world}", file=sys.stderr)
+        sys.exit(2)
+    return seen
+
+
+def stub_main(args):
+    """The N-rank launch, sharding, exchange and timing path with a torch CPU scan in place of
+    the HIP search and gloo in place of RCCL.  For tests of the launch path on a machine without
+    a GPU; the line it prints is marked data = stub-cpu and is never a measurement."""
+    import torch
+    import torch.distributed as dist
+    from rag_amd.sharded import ShardedIndex, shard_range
+
+    world, rank, local = rendezvous(args)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+    seen = check_world(dist, world)
+    device = torch.device("cpu")
+    rows, dim, k = min(args.rows, 20_000), min(args.dim, 64), args.k
+    lo, hi = shard_range(rows, rank, world)
+    g = torch.Generator().manual_seed(1234)
+    Xall = torch.randn((rows, dim), generator=g)
+    Xall /= Xall.norm(dim=1, keepdim=True)
+    X = Xall[lo:hi]
+    g.manual_seed(4321)
+    Q = torch.randn((64, dim), generator=g)
+    Q /= Q.norm(dim=1, keepdim=True)
+
+    def order_rule_topk(S, ids, kk):
+        # score descending, ties to the lower id: the order rule of the library
+        o = torch.argsort(ids, dim=1, stable=True)
+        S, ids = torch.gather(S, 1, o), torch.gather(ids, 1, o)
+        o = torch.argsort(S, dim=1, descending=True, stable=True)[:, :kk]
+        return torch.gather(S, 1, o), torch.gather(ids, 1, o)
+
+    def local_search(q, kk):
+        S = q @ X.T
+        ids = torch.arange(lo, hi, dtype=torch.int64)[None, :].expand(q.shape[0], -1)
+        D, I = order_rule_topk(S, ids, min(kk, hi - lo))
+        if D.shape[1] < kk:
+            pad = kk - D.shape[1]
+            D = torch.cat([D, torch.full((q.shape[0], pad), -3.4028234663852886e38)], 1)
+            I = torch.cat([I, torch.full((q.shape[0], pad), -1, dtype=torch.int64)], 1)
+        return D.contiguous(), I.contiguous()
+
+    def merge(D_all, I_all):
+        w, nq, kk = D_all.shape
+        S = D_all.permute(1, 0, 2).reshape(nq, w * kk)
+        ids = I_all.permute(1, 0, 2).reshape(nq, w * kk)
+        ids_sort = torch.where(ids < 0, torch.full_like(ids, 2 ** 62), ids)
+        D, I = order_rule_topk(S, ids_sort, kk)
+        return D, torch.where(I == 2 ** 62, torch.full_like(I, -1), I)
+
+    sharded = ShardedIndex(local_search=local_search, merge=merge)
+    search = sharded.search if world > 1 else local_search
+
+    def step(i):
+        j = i % Q.shape[0]
+        return search(Q[j:j + 1], k)
+
+    dt = timed_steps(torch, dist, world, step, args.warmup, args.steps, device)
+    # every rank must hold the answer of the whole corpus
+    D, I = search(Q[:8], k)
+    Dr, Ir = order_rule_topk(Q[:8] @ Xall.T, torch.arange(rows)[None, :].expand(8, -1), k)
+    ok = bool(torch.equal(I, Ir) and torch.allclose(D, Dr, rtol=1e-5, atol=1e-6))
+    flag = torch.tensor([1 if ok else 0])
+    if world > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print(json.dumps({
+            "metric": f"queries/sec, top-{k} exact IP, {rows}x{dim} fp32, batch 1", "value": args.steps / dt,
+            "unit": "queries/sec", "n_gpus": world, "world_size": seen, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "stub-cpu", "exchange_ok": bool(flag.item()),
+            "config": {"workload": "launch-path rehearsal: torch CPU scan + gloo, not a measurement",
+                       "rows": rows, "dim": dim, "k": k, "rows_per_gpu": hi - lo}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not flag.item():
+        sys.exit(4)
 
 
 def cpu_baseline(torch, X, Q, k, rows_total, big_batch):
@@ -163,20 +300,37 @@ def cpu_baseline(torch, X, Q, k, rows_total, big_batch):
     }
 
 
-def main():
-    args = parse()
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if args.gpus < 1:
+        print("error: --gpus must be >= 1", file=sys.stderr)
+        sys.exit(2)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: become the launcher (fresh rank processes; nothing here has touched the GPU)
+        sys.exit(spawn_ranks(args, argv))
+    if args.stub_cpu:
+        return stub_main(args)
+    world, rank, local = rendezvous(args)
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
+    if args.share_gpu and ndev > 0:
+        if args.dist_backend != "gloo":
+            print("error: --share-gpu needs --dist-backend gloo (RCCL wants one GPU per rank)", file=sys.stderr)
+            sys.exit(2)
+        local = local % ndev
+    if local >= ndev:
+        print(f"error: rank {rank} needs GPU {local} but {ndev} are visible", file=sys.stderr)
+        sys.exit(3)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using {world}", file=sys.stderr)
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend="gloo")
+    seen = check_world(dist, world)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 
@@ -292,7 +446,7 @@ def main():
     if rank == 0:
         out = {
             "metric": f"queries/sec, top-{k} exact IP, {args.rows}x{args.dim} fp32, batch 1",
-            "value": qps1, "unit": "queries/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": qps1, "unit": "queries/sec", "n_gpus": world, "world_size": seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt1 / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"exact flat top-{k}, {args.rows}x{args.dim} fp32 unit vectors "
@@ -300,7 +454,8 @@ def main():
                                    f"batch 1 (value) and batch {args.big_batch}",
                        "rows": args.rows, "dim": args.dim, "k": k, "batch": 1,
                        "rows_per_gpu": hi - lo, "path": path1,
-                       "exchange": "none" if world == 1 else "1 all-gather of (score,id) + device merge"},
+                       "exchange": "none" if world == 1 else "1 all-gather of (score,id) + device merge",
+                       "dist_backend": None if world == 1 else args.dist_backend},
             "roofline": roof1,
         }
         if big is not None:

@@ -179,7 +179,10 @@ int rag_fuse_maxnorm(int64_t n, const double* a, const double* b, const uint8_t*
 int rag_mmr_select(int64_t n, int d, const void* emb, int emb_is_f64, const double* rel,
                    double lambda, double similarity_threshold, int metric, int max_results,
                    int device, int32_t* out_idx, int32_t* n_out);
-/* same, embeddings taken from rows of an index (no host copy of vectors) */
+/* same, embeddings taken from rows of an index (no host copy of vectors; replaces the vector
+ * fetch of vector_db/search_manager.py:1699-1727).  rows[i] are ROW POSITIONS (insertion order,
+ * 0 .. ntotal-1), not ids: with an id base or explicit ids the caller maps ids back to positions.
+ * FLAT and IVF indexes alike (an IVF index translates positions to its list-ordered storage). */
 int rag_mmr_select_rows(rag_index_t* h, int64_t n, const int64_t* rows, const double* rel,
                         double lambda, double similarity_threshold, int metric,
                         int max_results, int32_t* out_idx, int32_t* n_out);

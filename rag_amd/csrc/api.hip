@@ -483,9 +483,9 @@ int rag_index_set_active(rag_index_t* h, int64_t n, const int64_t* rows, int act
     if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
     if (n < 0 || (n > 0 && !rows)) return fail(RAG_ERR_INVALID, "bad rows");
     if (n == 0) return RAG_OK;
+    RAG_LOCK_INDEX(h);
     for (int64_t i = 0; i < n; ++i)
         if (rows[i] < 0 || rows[i] >= h->n) return fail(RAG_ERR_INVALID, "row " + std::to_string(rows[i]) + " out of range");
-    RAG_LOCK_INDEX(h);
     DeviceGuard g(h->device);
     if (!h->active) {
         if (active) return RAG_OK;   // everything is active already
@@ -506,9 +506,9 @@ int rag_index_reconstruct(rag_index_t* h, int64_t n, const int64_t* rows, float*
     if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
     if (n < 0 || (n > 0 && (!rows || !out))) return fail(RAG_ERR_INVALID, "bad arguments");
     if (n == 0) return RAG_OK;
+    RAG_LOCK_INDEX(h);
     for (int64_t i = 0; i < n; ++i)
         if (rows[i] < 0 || rows[i] >= h->n) return fail(RAG_ERR_INVALID, "row " + std::to_string(rows[i]) + " out of range");
-    RAG_LOCK_INDEX(h);
     DeviceGuard g(h->device);
     const size_t rbytes = ((size_t)n * sizeof(long long) + 255) & ~(size_t)255;
     if (int rc = ws_acquire(h, h->stream)) return rc;
@@ -721,22 +721,9 @@ int rag_index_search_segments(rag_index_t* h, int64_t nq, const float* q, int64_
     return RAG_OK;
 }
 
-int rag_merge_topk_device(int nlists, int64_t nq, int k, const float* D_dev, int64_t d_list_stride, const int64_t* I_dev,
-                          int64_t i_list_stride, float* D_out_dev, int64_t* I_out_dev, int device, void* stream) {
-    if (d_list_stride == 0) d_list_stride = nq * k;
-    if (i_list_stride == 0) i_list_stride = nq * k;
-    if (d_list_stride < nq * k || i_list_stride < nq * k) return fail(RAG_ERR_INVALID, "list stride smaller than nq*k");
-    if (nlists < 1 || nq < 0 || k < 1 || k > 1024) return fail(RAG_ERR_INVALID, "bad nlists / nq / k");
-    if (nq == 0) return RAG_OK;
-    if (!D_dev || !I_dev || !D_out_dev || !I_out_dev) return fail(RAG_ERR_INVALID, "NULL buffer");
-    if ((long long)nlists * k > 0x7FFFFFFFLL) return fail(RAG_ERR_INVALID, "nlists * k too large");
-    DeviceGuard g(device);
-    if (!g.ok) return fail(RAG_ERR_HIP, "hipSetDevice failed");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    static thread_local Workspace keyws[64];
-    Workspace& ws = keyws[device & 63];
-    if (int rc = ws.ensure((size_t)nq * nlists * k * sizeof(u64))) return rc;
-    u64* keys = static_cast<u64*>(ws.ptr);
+// shared by the two merge entry points: argument checks, lists -> keys in `keys`, merge
+static int merge_topk_with_keys(int nlists, int64_t nq, int k, const float* D_dev, int64_t d_list_stride, const int64_t* I_dev,
+                                int64_t i_list_stride, float* D_out_dev, int64_t* I_out_dev, u64* keys, hipStream_t s) {
     RAG_HIP_CHECK(launch_lists_to_keys(nlists, nq, k, D_dev, d_list_stride, reinterpret_cast<const long long*>(I_dev), i_list_stride, keys, s));
     MergeArgs m = {};
     m.keys = keys;
@@ -752,6 +739,30 @@ int rag_merge_topk_device(int nlists, int64_t nq, int k, const float* D_dev, int
     m.I = reinterpret_cast<long long*>(I_out_dev);
     RAG_HIP_CHECK(launch_merge_keys(m, nq, s));
     return RAG_OK;
+}
+
+static int merge_topk_check(int nlists, int64_t nq, int k, const float* D_dev, int64_t& d_list_stride, const int64_t* I_dev,
+                            int64_t& i_list_stride, float* D_out_dev, int64_t* I_out_dev) {
+    if (nlists < 1 || nq < 0 || k < 1 || k > 1024) return fail(RAG_ERR_INVALID, "bad nlists / nq / k");
+    if (d_list_stride == 0) d_list_stride = nq * k;
+    if (i_list_stride == 0) i_list_stride = nq * k;
+    if (d_list_stride < nq * k || i_list_stride < nq * k) return fail(RAG_ERR_INVALID, "list stride smaller than nq*k");
+    if (nq > 0 && (!D_dev || !I_dev || !D_out_dev || !I_out_dev)) return fail(RAG_ERR_INVALID, "NULL buffer");
+    if ((long long)nlists * k > 0x7FFFFFFFLL) return fail(RAG_ERR_INVALID, "nlists * k too large");
+    return RAG_OK;
+}
+
+int rag_merge_topk_device(int nlists, int64_t nq, int k, const float* D_dev, int64_t d_list_stride, const int64_t* I_dev,
+                          int64_t i_list_stride, float* D_out_dev, int64_t* I_out_dev, int device, void* stream) {
+    if (int rc = merge_topk_check(nlists, nq, k, D_dev, d_list_stride, I_dev, i_list_stride, D_out_dev, I_out_dev)) return rc;
+    if (nq == 0) return RAG_OK;
+    DeviceGuard g(device);
+    if (!g.ok) return fail(RAG_ERR_HIP, "hipSetDevice failed");
+    static thread_local Workspace keyws[64];
+    Workspace& ws = keyws[device & 63];
+    if (int rc = ws.ensure((size_t)nq * nlists * k * sizeof(u64))) return rc;
+    return merge_topk_with_keys(nlists, nq, k, D_dev, d_list_stride, I_dev, i_list_stride, D_out_dev, I_out_dev,
+                                static_cast<u64*>(ws.ptr), static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -278,6 +278,8 @@ __global__ __launch_bounds__(MMR_WAVES * 64) void mmr_round_kernel(MmrArgs p, Mm
     }
 }
 
+int ivf_reconstruct_rows(rag_index* h, long long n, const int64_t* rows, std::vector<long long>& storage_rows);   // ivf.hip
+
 static thread_local Workspace g_fuse_ws[64];
 
 static int current_device(int* dev) {
@@ -460,7 +462,14 @@ int rag_mmr_select_rows(rag_index_t* h, int64_t n, const int64_t* rows, const do
     if (n > 0 && !rows) return fail(RAG_ERR_INVALID, "rows is NULL");
     for (int64_t i = 0; i < n; ++i)
         if (rows[i] < 0 || rows[i] >= h->n) return fail(RAG_ERR_INVALID, "row " + std::to_string(rows[i]) + " out of range");
-    return run_mmr(h->device, n, h->dim, nullptr, 0, h->X, h->ld, reinterpret_cast<const long long*>(rows), rel, lambda,
+    // an IVF index keeps its rows grouped by list: insertion position -> storage position
+    std::vector<long long> storage_rows;
+    const long long* where = reinterpret_cast<const long long*>(rows);
+    if (h->kind == RAG_KIND_IVF && n > 0) {
+        if (int rc = ivf_reconstruct_rows(h, n, rows, storage_rows)) return rc;
+        where = storage_rows.data();
+    }
+    return run_mmr(h->device, n, h->dim, nullptr, 0, h->X, h->ld, where, rel, lambda,
                    similarity_threshold, metric, max_results, out_idx, n_out);
 }
 

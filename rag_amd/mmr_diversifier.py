@@ -48,7 +48,8 @@ def mmr_select_rows(index, rows: Sequence[int], relevance: Sequence[float], lamb
                     similarity_threshold: float, metric: str, max_results: int) -> List[int]:
     """Same selection with the embeddings taken from rows of a ``DeviceIndex``
     (nothing is copied to the host; replaces the per-result vector fetch of
-    vector_db/search_manager.py:1699-1727)."""
+    vector_db/search_manager.py:1699-1727).  ``rows`` are row positions (insertion order), not
+    ids: subtract the id base / map explicit ids back before calling.  Flat and IVF indexes."""
     rows = np.ascontiguousarray(rows, dtype=np.int64)
     rel = np.ascontiguousarray(relevance, dtype=np.float64)
     n = rows.size

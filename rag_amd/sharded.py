@@ -27,6 +27,16 @@ def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, hi
 
 
+def slot_layout(nq: int, k: int):
+    """Layout of one rank's slot in the all-gather buffer, in the terms rag_merge_topk_device
+    takes them.  A slot is ``words`` int64 words: nq*k ids, then nq*k fp32 scores packed two to a
+    word.  Returns (words, score_offset_bytes, d_list_stride in floats, i_list_stride in int64s);
+    slot g of the gathered buffer starts g*words words in."""
+    nk = nq * k
+    words = nk + (nk + 1) // 2
+    return words, nk * 8, words * 2, words
+
+
 class ShardedIndex:
     """``local_search(q, k, **kw) -> (D, I)`` with global ids, and
     ``merge(D_all, I_all) -> (D, I)`` for ``[world, nq, k]`` stacks.  By default
@@ -63,20 +73,29 @@ class ShardedIndex:
         if q.dim() == 1:
             q = q[None, :]
         nq = q.shape[0]
-        nk = nq * k
-        slot = nk + (nk + 1) // 2
-        shape = (self.world, slot)
+        slot, d_off, d_stride, i_stride = slot_layout(nq, k)
+        shape = (self.world * slot,)       # flat: every backend takes the concatenation form
         if self._gather_buf is None or self._gather_buf.shape != shape or self._gather_buf.device != q.device:
             self._gather_buf = torch.empty(shape, dtype=torch.int64, device=q.device)
             self._send_buf = torch.empty((slot,), dtype=torch.int64, device=q.device)
         buf = self._gather_buf
         mine = self._send_buf
         i_ptr = mine.data_ptr()
-        d_ptr = i_ptr + nk * 8
-        self.index.search_into(q, k, d_ptr, i_ptr, **kw)
-        self.dist.all_gather_into_tensor(buf, mine, group=self.group)
-        return merge_topk_strided(self.world, nq, k, buf.data_ptr() + nk * 8, slot * 2, buf.data_ptr(), slot,
+        self.index.search_into(q, k, i_ptr + d_off, i_ptr, **kw)
+        self._all_gather(buf, mine)
+        return merge_topk_strided(self.world, nq, k, buf.data_ptr() + d_off, d_stride, buf.data_ptr(), i_stride,
                                   q.device)
+
+    def _all_gather(self, out, mine):
+        """The path's one exchange.  RCCL gathers device buffers in place; a gloo group (CPU
+        rehearsals of the multi-rank path, several ranks sharing one GPU) is fed host copies."""
+        if self.dist.is_initialized() and self.dist.get_backend(self.group) == "gloo" and mine.is_cuda:
+            import torch
+            host_out = torch.empty(out.shape, dtype=out.dtype)
+            self.dist.all_gather_into_tensor(host_out, mine.cpu(), group=self.group)
+            out.copy_(host_out)
+            return
+        self.dist.all_gather_into_tensor(out, mine, group=self.group)
 
     def search(self, q, k: int, **kw):
         import torch

@@ -112,3 +112,46 @@ def test_row_sharded_ivf_equals_one_index():
     assert np.array_equal(Im.cpu().numpy(), If)
     assert np.array_equal(Dm.cpu().numpy(), Df)
     full.close()
+
+
+def test_mmr_on_rows_of_an_ivf_index():
+    """MMR over rows of an IVF index (stored grouped by list): search -> MMR on the returned
+    positions == the oracle's MMR on the host copies of those rows, between adds (unsorted tail),
+    after the re-pack, and with an id base (ids = base + position)."""
+    from oracle import mmr as omrr
+    from rag_amd import DeviceIndex
+    from rag_amd.mmr_diversifier import mmr_select_rows, normalise_relevance
+    rng = np.random.default_rng(17)
+    n, d, nlist = 12_000, 256, 32
+    cent = rng.standard_normal((30, d))
+    X = cent[rng.integers(0, 30, n)] + 0.25 * rng.standard_normal((n, d))
+    X = (X / np.linalg.norm(X, axis=1, keepdims=True)).astype(np.float32)
+    C = X[rng.choice(n, nlist, replace=False)].copy()
+    q = (cent[4] / np.linalg.norm(cent[4])).astype(np.float32)
+    base = 7_000_000
+    idx = DeviceIndex(d, metric="ip", kind="ivf")
+    idx.train_ivf(nlist, centroids=C)
+    idx.set_id_base(base)
+    idx.add(X[:5000])
+
+    def check(nrows):
+        D, I = idx.search(q, 150, nprobe=nlist)
+        rows = I[0] - base                                   # ids -> row positions
+        assert rows.min() >= 0 and rows.max() < nrows
+        assert np.array_equal(idx.reconstruct(rows), X[rows])
+        rel = normalise_relevance([float(s) for s in D[0]])
+        for lam, thr, metric in ((0.5, 0.8, "cosine"), (0.3, 0.5, "cosine"), (0.6, 0.0, "dot_product")):
+            want = omrr.mmr_select_fast(X[rows].astype(np.float64), [float(s) for s in D[0]], lam, 10, thr, metric)
+            got = mmr_select_rows(idx, rows, rel, lam, thr, metric, 10)
+            assert got == want, (nrows, lam, thr, metric)
+        return rows
+
+    check(5000)
+    idx.add(X[5000:])
+    # rows added since the last search sit unsorted at the tail until the next search re-packs
+    tail = np.arange(4990, 5300)
+    rel = normalise_relevance(list(np.linspace(1.0, 0.0, tail.size)))
+    want = omrr.mmr_select_fast(X[tail].astype(np.float64), list(np.linspace(1.0, 0.0, tail.size)), 0.5, 12, 0.7, "cosine")
+    assert mmr_select_rows(idx, tail, rel, 0.5, 0.7, "cosine", 12) == want
+    check(n)
+    idx.close()
