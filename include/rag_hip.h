@@ -139,6 +139,19 @@ int rag_merge_topk_device(int nlists, int64_t nq, int k, const float* D_dev, int
                           const int64_t* I_dev, int64_t i_list_stride, float* D_out_dev,
                           int64_t* I_out_dev, int device, void* stream);
 
+/* The same merge for callers that cannot allocate (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  It calls no
+ * hipMalloc / hipFree: its candidate keys live in a static device array of the library, one copy
+ * per GPU held until the process ends (RAG_MERGE_STATIC_MAX_KEYS * 8 bytes = 8 MiB).  Limit:
+ * nq * nlists * k <= RAG_MERGE_STATIC_MAX_KEYS, beyond which it returns RAG_ERR_INVALID.  Every
+ * call on a GPU shares that GPU's array: calls that overlap on one GPU (different streams or
+ * threads) race; calls on one stream are ordered.  Same arguments and results as
+ * rag_merge_topk_device. */
+#define RAG_MERGE_STATIC_MAX_KEYS (1 << 20)
+int rag_merge_topk_device_static(int nlists, int64_t nq, int k, const float* D_dev, int64_t d_list_stride,
+                                 const int64_t* I_dev, int64_t i_list_stride, float* D_out_dev,
+                                 int64_t* I_out_dev, int device, void* stream);
+
 /* measurement: while enabled, every search records a HIP event pair around its
  * dominant kernel (the corpus scan / GEMM) on the search's stream.  read
  * synchronises those events and returns the summed kernel time and the number

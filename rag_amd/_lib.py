@@ -53,6 +53,7 @@ SIGNATURES = {
     "rag_index_search_segments": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _f32, _vp, _vp, _vp]),
     "rag_index_last_path": (C.c_char_p, [_vp]),
     "rag_merge_topk_device": (_i32, [_i32, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _vp]),
+    "rag_merge_topk_device_static": (_i32, [_i32, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _vp]),
     "rag_index_profile_enable": (_i32, [_vp, _i32]),
     "rag_index_profile_read": (_i32, [_vp, C.POINTER(_f64), C.POINTER(_i64), _i32]),
     "rag_index_train_ivf": (_i32, [_vp, _i32, _vp, _i64, _vp]),

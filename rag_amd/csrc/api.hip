@@ -766,3 +766,50 @@ int rag_merge_topk_device(int nlists, int64_t nq, int k, const float* D_dev, int
 }
 
 }  // extern "C"
+
+// ---- the merge without any allocation -------------------------------------------------------
+// The candidate keys of rag_merge_topk_device_static live in this array of the code object
+// instead of a hipMalloc'd workspace.  Every GPU the library runs on holds its own copy at its own
+// address for the life of the process; host code reaches it only through the address
+// hipGetSymbolAddress returns for the current device (the name below is a host-side stand-in).
+static __device__ __align__(256) unsigned char scratch[RAG_MERGE_STATIC_MAX_KEYS * sizeof(unsigned long long)];
+
+namespace rag {
+static std::mutex g_scratch_mu;
+static void* g_scratch_ptr[64] = {};      // per device, filled on the first call on that device
+
+// device address of `scratch` on `device` (which must be current)
+static int scratch_address(int device, void** out) {
+    if (device < 0 || device >= 64) return fail(RAG_ERR_INVALID, "device out of range");
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) return fail(RAG_ERR_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return RAG_OK;
+}
+}  // namespace rag
+
+extern "C" {
+
+int rag_merge_topk_device_static(int nlists, int64_t nq, int k, const float* D_dev, int64_t d_list_stride, const int64_t* I_dev,
+                                 int64_t i_list_stride, float* D_out_dev, int64_t* I_out_dev, int device, void* stream) {
+    if (int rc = merge_topk_check(nlists, nq, k, D_dev, d_list_stride, I_dev, i_list_stride, D_out_dev, I_out_dev)) return rc;
+    if (nq == 0) return RAG_OK;
+    if (nq > RAG_MERGE_STATIC_MAX_KEYS || (long long)nq * nlists * k > RAG_MERGE_STATIC_MAX_KEYS)
+        return fail(RAG_ERR_INVALID, "nq * nlists * k = " + std::to_string((long long)nq * nlists * k) + " keys exceed the static scratch of " +
+                                         std::to_string((long long)RAG_MERGE_STATIC_MAX_KEYS) + " keys; use rag_merge_topk_device");
+    DeviceGuard g(device);
+    if (!g.ok) return fail(RAG_ERR_HIP, "hipSetDevice failed");
+    void* keys = nullptr;
+    if (int rc = scratch_address(device, &keys)) return rc;
+    // every key slot [0, nq*nlists*k) is written by the conversion kernel before the merge reads
+    // it, so nothing of the previous call's contents has to be cleared
+    return merge_topk_with_keys(nlists, nq, k, D_dev, d_list_stride, I_dev, i_list_stride, D_out_dev, I_out_dev,
+                                static_cast<u64*>(keys), static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"
