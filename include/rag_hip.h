@@ -200,6 +200,56 @@ int rag_mmr_select_rows(rag_index_t* h, int64_t n, const int64_t* rows, const do
                         double lambda, double similarity_threshold, int metric,
                         int max_results, int32_t* out_idx, int32_t* n_out);
 
+/* ---- search -> hybrid fusion -> MMR as one enqueue ---------------------------------
+ * vector_db/search_manager.py:938-970 (_contextual_search: semantic hits + keyword hits ->
+ * _combine_semantic_and_bm25_contextual, :1023-1101 -> stable sort descending -> cut) followed
+ * by :1620-1681 (_apply_mmr_diversification; vectors come from the index rows instead of the
+ * per-result fetch of :1683-1735).  One query.  The steps run back to back on one stream;
+ * candidate lists, fused scores and the fp64 rows MMR reads stay in device memory throughout.
+ *   topn            semantic hits to fetch (1..1024), with min_score / nprobe / row_mask as in
+ *                   rag_index_search
+ *   bm25_rows/scores nb (0..1024) keyword hits as (row POSITION, BM25 score); positions outside
+ *                   [0, ntotal) are ignored; a repeated row keeps its later score and both
+ *                   maxima run over every entry, as the dicts of :1032-1046 do
+ *   w_sem, w_bm25   0.65 / 0.35 in the reference (:1072-1075); each side is divided by its own
+ *                   maximum (an empty side by 1.0); a zero maximum is the reference's
+ *                   ZeroDivisionError path (:1098-1101): status = 1 and the semantic list with
+ *                   its raw scores takes the place of the fused list
+ *   fuse_limit      the fused list (semantic hits first, then keyword-only rows in order of first
+ *                   appearance; stable sort by fused score descending) is cut to this many (1..1024)
+ *   MMR             relevance = min-max of the kept fused scores (all equal -> 1.0),
+ *                   vector_db/mmr_diversifier.py:188-289 with lambda / threshold / metric,
+ *                   max_results picks
+ * Results (pointers in rag_hybrid_out_t; ids, scores, n_out required, the rest may be NULL):
+ *   ids/scores/picked [max_results] final hits in selection order: id, fused score, position in
+ *   the fused list; n_out their count; fused_rows/scores/sem/bm [fuse_limit] the fused list (row
+ *   position, fused score, normalised semantic / keyword score); n_fused; status. */
+typedef struct rag_hybrid_out {
+    int64_t* ids;
+    double* scores;
+    int32_t* picked;
+    int32_t* n_out;
+    int64_t* fused_rows;
+    double* fused_scores;
+    double* fused_sem;
+    double* fused_bm;
+    int32_t* n_fused;
+    int32_t* status;
+} rag_hybrid_out_t;
+/* host pointers; returns when the results are in the caller's arrays (one synchronisation at the end) */
+int rag_index_hybrid_mmr(rag_index_t* h, const float* q, int topn, float min_score, int nprobe,
+                         const uint8_t* row_mask, int64_t nb, const int64_t* bm25_rows,
+                         const double* bm25_scores, double w_sem, double w_bm25, int fuse_limit,
+                         double mmr_lambda, double mmr_threshold, int mmr_metric, int max_results,
+                         const rag_hybrid_out_t* out);
+/* every buffer (and every pointer inside *out_dev; the struct itself is host memory) in device
+ * memory; enqueued on `stream` and not synchronised */
+int rag_index_hybrid_mmr_device(rag_index_t* h, const float* q_dev, int topn, float min_score, int nprobe,
+                                const uint8_t* row_mask_dev, int64_t nb, const int64_t* bm25_rows_dev,
+                                const double* bm25_scores_dev, double w_sem, double w_bm25,
+                                int fuse_limit, double mmr_lambda, double mmr_threshold, int mmr_metric,
+                                int max_results, const rag_hybrid_out_t* out_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,7 +61,17 @@ SIGNATURES = {
     "rag_fuse_maxnorm": (_i32, [_i64, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _f64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "rag_mmr_select": (_i32, [_i64, _i32, _vp, _i32, _vp, _f64, _f64, _i32, _i32, _i32, _vp, _vp]),
     "rag_mmr_select_rows": (_i32, [_vp, _i64, _vp, _vp, _f64, _f64, _i32, _i32, _vp, _vp]),
+    "rag_index_hybrid_mmr": (_i32, [_vp, _vp, _i32, _f32, _i32, _vp, _i64, _vp, _vp, _f64, _f64, _i32, _f64, _f64, _i32,
+                                    _i32, _vp]),
+    "rag_index_hybrid_mmr_device": (_i32, [_vp, _vp, _i32, _f32, _i32, _vp, _i64, _vp, _vp, _f64, _f64, _i32, _f64, _f64,
+                                           _i32, _i32, _vp, _vp]),
 }
+
+
+class HybridOut(C.Structure):
+    """rag_hybrid_out_t: where the search -> fusion -> MMR pipeline leaves its results."""
+    _fields_ = [("ids", _vp), ("scores", _vp), ("picked", _vp), ("n_out", _vp), ("fused_rows", _vp),
+                ("fused_scores", _vp), ("fused_sem", _vp), ("fused_bm", _vp), ("n_fused", _vp), ("status", _vp)]
 
 
 def _load():

@@ -258,6 +258,7 @@ static int flat_scan_search(rag_index* h, long long nq, const float* qbuf, int k
         m.min_score = min_score;
         m.row_ids = h->ids_dev;
         m.id_base = h->id_base;
+    m.rows_out = h->merge_rows_out;
         m.slot_ids = nullptr;
         m.slot_stride = 0;
         m.D = D + q0 * k;
@@ -349,6 +350,7 @@ int rag_index_free(rag_index_t* h) {
     ivf_free(h);
     h->ws.release();
     h->ws2.release();
+    h->ws3.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return RAG_OK;
@@ -588,6 +590,18 @@ static int search_device_ordered(rag_index* h, int64_t nq, const float* q_dev, i
     return flat_search_prepared(h, nq, qbuf, k, min_score, mask, D_dev, I, s);
 }
 
+}  // extern "C"
+
+namespace rag {
+// a search enqueued for another entry point of the library (index locked, device current, workspaces acquired)
+int search_device_enqueue(rag_index* h, int64_t nq, const float* q_dev, int k, float min_score, int nprobe,
+                          const uint8_t* row_mask_dev, float* D_dev, int64_t* I_dev, hipStream_t s) {
+    return search_device_ordered(h, nq, q_dev, k, min_score, nprobe, row_mask_dev, D_dev, I_dev, s);
+}
+}  // namespace rag
+
+extern "C" {
+
 int rag_index_search(rag_index_t* h, int64_t nq, const float* q, int k, float min_score, int nprobe,
                      const uint8_t* row_mask, float* D, int64_t* I) {
     if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
@@ -710,6 +724,7 @@ int rag_index_search_segments(rag_index_t* h, int64_t nq, const float* q, int64_
     m.min_score = min_score;
     m.row_ids = h->ids_dev;
     m.id_base = h->id_base;
+    m.rows_out = h->merge_rows_out;
     m.D = D_dev;
     m.I = I_dev;
     RAG_HIP_CHECK(launch_merge_keys(m, nq * nseg, s));

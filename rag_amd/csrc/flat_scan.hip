@@ -341,6 +341,7 @@ __device__ __forceinline__ void finalise_hit(const MergeArgs& a, long long q, in
     }
     a.D[(size_t)q * k + j] = s;
     a.I[(size_t)q * k + j] = id;
+    if (a.rows_out) a.rows_out[(size_t)q * k + j] = s < -3.0e38f ? -1 : (long long)key_row(key);
 }
 
 // ---------------------------------------------------------------------------

@@ -9,8 +9,10 @@
 // candidate set never has to leave the GPU between search, fusion and MMR.
 #include <float.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "index.h"
@@ -119,6 +121,8 @@ struct MmrArgs {
     const void* emb;      // [n][d] fp32 or fp64 (host copy) ...
     const float* X;       // ... or rows of an index: X[rows[i]*ld + j]
     const long long* rows;
+    const long long* pos;  // optional: row position -> storage position (IVF indexes keep rows grouped by list)
+    const int* n_dev;      // optional: the candidate count lives on the device (<= n, which then sizes the grids)
     int ld;
     int emb_is_f64;
     double* En;           // [n][d] workspace: rows as the similarity uses them
@@ -148,10 +152,16 @@ struct MmrState {
 __global__ __launch_bounds__(64) void mmr_prepare_kernel(MmrArgs p, MmrState st) {
     const int lane = threadIdx.x, d = p.d;
     const int c = blockIdx.x;
+    if (p.n_dev && c >= *p.n_dev) return;
+    long long xr = 0;
+    if (p.X) {
+        xr = p.rows[c];
+        if (p.pos) xr = p.pos[xr];
+    }
     double ss = 0.0;
     for (int j = lane; j < d; j += 64) {
         double v;
-        if (p.X) v = (double)p.X[p.rows[c] * (long long)p.ld + j];
+        if (p.X) v = (double)p.X[xr * (long long)p.ld + j];
         else if (p.emb_is_f64) v = static_cast<const double*>(p.emb)[(size_t)c * d + j];
         else v = (double)static_cast<const float*>(p.emb)[(size_t)c * d + j];
         p.En[(size_t)c * d + j] = v;
@@ -163,7 +173,7 @@ __global__ __launch_bounds__(64) void mmr_prepare_kernel(MmrArgs p, MmrState st)
         if (nrm == 0.0) nrm = 1.0;
         for (int j = lane; j < d; j += 64) p.En[(size_t)c * d + j] = p.En[(size_t)c * d + j] / nrm;
     }
-    if (lane == 0) { st.maxsim[c] = -INFINITY; st.alive[c] = 1; }
+    if (lane == 0 && st.maxsim) { st.maxsim[c] = -INFINITY; st.alive[c] = 1; }
 }
 
 __device__ __forceinline__ bool mmr_better(double ob, int oi, double best, int bidx) {
@@ -280,6 +290,302 @@ __global__ __launch_bounds__(MMR_WAVES * 64) void mmr_round_kernel(MmrArgs p, Mm
 
 int ivf_reconstruct_rows(rag_index* h, long long n, const int64_t* rows, std::vector<long long>& storage_rows);   // ivf.hip
 
+// ---------------------------------------------------------------------------
+// Small candidate sets (n <= MMR_SIM_MAX_N, the reference's top-200): the whole selection in three
+// launches instead of one per round.  mmr_simmat_kernel computes the similarity of every candidate
+// pair with the arithmetic of mmr_round_kernel (per lane an fma chain over j = lane, lane + 64, ...,
+// then the xor-shuffle tree), so S[c][s] is bit for bit the value a round would compute; the
+// matrix is symmetric bit for bit (products and squared differences commute).  mmr_select_kernel
+// then runs every round in ONE workgroup: a round is a row read of S (the row of the candidate
+// selected last) and an argmax over the workgroup.
+constexpr int MMR_SIM_MAX_N = 1024;
+constexpr int SIM_TC = 8, SIM_TS = 8;      // candidates x selected rows per workgroup
+__global__ __launch_bounds__(256) void mmr_simmat_kernel(const double* En, const int* n_dev, int n_max, int d, int metric,
+                                                         double* S, int ldS) {
+    const int n = n_dev ? *n_dev : n_max;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * SIM_TC + wave * 2;
+    const int s0 = blockIdx.y * SIM_TS;
+    if (c0 >= n || s0 >= n) return;
+    const int c1 = c0 + 1 < n ? c0 + 1 : c0;
+    const double* e0 = En + (size_t)c0 * d;
+    const double* e1 = En + (size_t)c1 * d;
+    for (int si = 0; si < SIM_TS; ++si) {
+        const int sr = s0 + si;
+        if (sr >= n) break;
+        const double* es = En + (size_t)sr * d;
+        double a0 = 0.0, a1 = 0.0;
+        if (metric == RAG_MMR_EUCLIDEAN) {
+#pragma unroll 4
+            for (int j = lane; j < d; j += 64) {
+                const double e = es[j];
+                const double f0 = e0[j] - e, f1 = e1[j] - e;
+                a0 = fma(f0, f0, a0);
+                a1 = fma(f1, f1, a1);
+            }
+        } else {
+#pragma unroll 4
+            for (int j = lane; j < d; j += 64) {
+                const double e = es[j];
+                a0 = fma(e0[j], e, a0);
+                a1 = fma(e1[j], e, a1);
+            }
+        }
+        a0 = wave_sum_f64(a0);
+        a1 = wave_sum_f64(a1);
+        if (metric == RAG_MMR_EUCLIDEAN) { a0 = 1.0 / (1.0 + sqrt(a0)); a1 = 1.0 / (1.0 + sqrt(a1)); }
+        if (lane == 0) {
+            S[(size_t)c0 * ldS + sr] = a0;
+            if (c0 + 1 < n) S[(size_t)(c0 + 1) * ldS + sr] = a1;
+        }
+    }
+}
+
+struct MmrSelArgs {
+    const double* S;      // [n][ldS] pair similarities
+    int ldS;
+    const double* rel;    // [n] normalised relevance
+    const int* n_dev;     // optional device-side candidate count (<= n_max)
+    int n_max;
+    double lambda, threshold;
+    int max_results;
+    int* out_idx;         // [max_results] candidate positions in selection order
+    int* n_out;
+    // optional epilogue (search -> fusion -> MMR in one enqueue): candidate position -> (id, fused score)
+    const long long* cand_rows;
+    const double* cand_score;
+    const long long* row_ids;
+    long long id_base;
+    long long* out_ids;
+    double* out_scores;
+};
+
+__global__ __launch_bounds__(1024) void mmr_select_kernel(MmrSelArgs p) {
+    __shared__ double s_b[16];
+    __shared__ int s_i[16];
+    __shared__ int s_sel;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = p.n_dev ? *p.n_dev : p.n_max;
+    const int c = tid;
+    bool alive = c < n;
+    const double rel = alive ? p.rel[c] : 0.0;
+    double maxsim = -INFINITY;
+    const int rounds = p.max_results < n ? p.max_results : n;
+    int sel = -1;
+    for (int r = 0; r < rounds; ++r) {
+        double best = -INFINITY;
+        int bidx = 0x7FFFFFFF;
+        if (alive) {
+            double m = 0.0;
+            if (sel >= 0) {
+                const double v = p.S[(size_t)sel * p.ldS + c];
+                if (v > maxsim) maxsim = v;
+                m = maxsim;
+                if (m < p.threshold) m = 0.0;
+            }
+            const double v = __dsub_rn(__dmul_rn(p.lambda, rel), __dmul_rn(1.0 - p.lambda, m));
+            bidx = c;
+            best = (v > -INFINITY) ? v : -INFINITY;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ob = __shfl_xor(best, off, 64);
+            const int oi = __shfl_xor(bidx, off, 64);
+            if (mmr_better(ob, oi, best, bidx)) { best = ob; bidx = oi; }
+        }
+        if (lane == 0) { s_b[wave] = best; s_i[wave] = bidx; }
+        __syncthreads();
+        if (wave == 0) {
+            best = lane < 16 ? s_b[lane] : -INFINITY;
+            bidx = lane < 16 ? s_i[lane] : 0x7FFFFFFF;
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) {
+                const double ob = __shfl_xor(best, off, 64);
+                const int oi = __shfl_xor(bidx, off, 64);
+                if (mmr_better(ob, oi, best, bidx)) { best = ob; bidx = oi; }
+            }
+            if (lane == 0) s_sel = bidx;
+        }
+        __syncthreads();
+        sel = s_sel;
+        if (sel == 0x7FFFFFFF) { sel = -1; break; }          // cannot happen while rounds <= n
+        if (c == sel) alive = false;
+        if (tid == 0) {
+            p.out_idx[r] = sel;
+            if (p.out_ids) {
+                const long long row = p.cand_rows[sel];
+                p.out_ids[r] = p.row_ids ? p.row_ids[row] : p.id_base + row;
+                p.out_scores[r] = p.cand_score[sel];
+            }
+        }
+    }
+    if (tid == 0) *p.n_out = rounds;
+}
+
+// ---------------------------------------------------------------------------
+// Hybrid fusion of a semantic hit list with a keyword (BM25) list, both already on the device
+// (vector_db/search_manager.py:1023-1101 and the caller's sort + cut, :969-970), followed by the
+// relevance normalisation MMR starts with (vector_db/mmr_diversifier.py:188-200).  Candidates are
+// identified by row position.  One workgroup.
+//   candidates   the semantic hits in order, then the keyword-only rows in order of first appearance
+//   a repeated keyword row keeps the later score (dict semantics, :1036-1039); both maxima run over
+//   every entry (:1042-1043); an empty side divides by 1.0 (:1045-1046)
+//   a zero maximum is the reference's ZeroDivisionError path (:1098-1101): status = 1 and the
+//   semantic list comes back with its raw scores
+constexpr int HYB_MAX_SEM = 1024, HYB_MAX_BM = 1024;
+struct HybridArgs {
+    const float* D;              // [topn] semantic scores, best first
+    const long long* rows;       // [topn] row positions, -1 = unfilled (a suffix)
+    int topn;
+    const long long* bm_rows;    // [nb] row positions of the keyword hits (outside [0, nrows): ignored)
+    const double* bm_scores;     // [nb]
+    int nb;
+    long long nrows;
+    double wa, wb;
+    int limit;                   // fused list is cut to this many
+    long long* f_rows;           // [limit] out: candidates best first
+    double* f_score;             // [limit]
+    double* f_sem;               // [limit] normalised semantic score (0 where absent)
+    double* f_bm;                // [limit]
+    unsigned char* f_flags;      // [limit] bit 0 = has semantic, bit 1 = has keyword
+    double* rel;                 // [limit] min-max normalised fused score (all equal -> 1.0)
+    int* n_fused;
+    int* status;                 // 0 fused, 1 zero maximum (semantic list returned)
+};
+
+__global__ __launch_bounds__(1024) void hybrid_fuse_kernel(HybridArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int NC = p.topn + p.nb;                       // candidate slots
+    int npad = 2;
+    while (npad < NC) npad <<= 1;
+    // [0, 64): counters and maxima; all LDS of the kernel is in the dynamic region (16-byte aligned base)
+    int& s_nsem = *reinterpret_cast<int*>(smem);
+    int& s_nbvalid = *reinterpret_cast<int*>(smem + 4);
+    int& s_nonly = *reinterpret_cast<int*>(smem + 8);
+    int& s_kept = *reinterpret_cast<int*>(smem + 12);
+    unsigned long long& s_maxsem = *reinterpret_cast<unsigned long long*>(smem + 16);     // ordered fp64 bits
+    unsigned long long& s_maxbm = *reinterpret_cast<unsigned long long*>(smem + 24);
+    SortEntry* e = reinterpret_cast<SortEntry*>(smem + 64);                        // [npad]
+    double* c_sem = reinterpret_cast<double*>(e + npad);                           // [NC]
+    double* c_bm = c_sem + NC;                                                     // [NC]
+    double* c_sc = c_bm + NC;                                                      // [NC]
+    long long* c_row = reinterpret_cast<long long*>(c_sc + NC);                    // [NC]
+    int* bm_first = reinterpret_cast<int*>(c_row + NC);                            // [nb] first valid appearance and keyword-only
+    int* bm_match = bm_first + p.nb;                                               // [nb] semantic hit with the same row, or -1
+    unsigned char* c_fl = reinterpret_cast<unsigned char*>(bm_match + p.nb);       // [NC]
+    if (tid == 0) { s_nsem = 0; s_nbvalid = 0; s_nonly = 0; s_kept = 0; s_maxsem = 0ull; s_maxbm = 0ull; }
+    __syncthreads();
+    // semantic side
+    for (int i = tid; i < p.topn; i += 1024) {
+        const long long r = p.rows[i];
+        c_fl[i] = 0;
+        c_bm[i] = 0.0;
+        if (r >= 0) {
+            const double sv = (double)p.D[i];
+            c_row[i] = r;
+            c_sem[i] = sv;
+            c_fl[i] = 1;
+            atomicAdd(&s_nsem, 1);
+            atomicMax(&s_maxsem, f64_ordered(sv));
+        }
+    }
+    __syncthreads();
+    const int nsem = s_nsem;
+    // keyword side: validity, duplicates (the later score wins, the first appearance keeps the place)
+    for (int j = tid; j < p.nb; j += 1024) {
+        const long long r = p.bm_rows[j];
+        int first = 0, match = -1;
+        if (r >= 0 && r < p.nrows) {
+            atomicAdd(&s_nbvalid, 1);
+            atomicMax(&s_maxbm, f64_ordered(p.bm_scores[j]));
+            first = 1;
+            for (int j2 = 0; j2 < j; ++j2)
+                if (p.bm_rows[j2] == r) { first = 0; break; }
+            if (first) {
+                for (int i = 0; i < nsem; ++i)
+                    if (p.rows[i] == r) { match = i; break; }
+            }
+        }
+        bm_first[j] = first;
+        bm_match[j] = match;
+    }
+    __syncthreads();
+    for (int j = tid; j < p.nb; j += 1024) {
+        if (!bm_first[j]) continue;
+        const long long r = p.bm_rows[j];
+        double val = p.bm_scores[j];
+        for (int j2 = j + 1; j2 < p.nb; ++j2)
+            if (p.bm_rows[j2] == r) val = p.bm_scores[j2];
+        int slot = bm_match[j];
+        if (slot < 0) {
+            int before = 0;
+            for (int j2 = 0; j2 < j; ++j2) before += (bm_first[j2] && bm_match[j2] < 0) ? 1 : 0;
+            slot = nsem + before;
+            c_row[slot] = r;
+            c_sem[slot] = 0.0;
+            c_fl[slot] = 0;
+            atomicAdd(&s_nonly, 1);
+        }
+        c_bm[slot] = val;
+        c_fl[slot] |= 2;
+    }
+    __syncthreads();
+    const int ncand = nsem + s_nonly;
+    auto unordered = [](unsigned long long o) { return __longlong_as_double((long long)((o >> 63) ? (o & 0x7FFFFFFFFFFFFFFFull) : ~o)); };
+    const double max_sem = nsem > 0 ? unordered(s_maxsem) : 1.0;
+    const double max_bm = s_nbvalid > 0 ? unordered(s_maxbm) : 1.0;
+    const bool zero_div = (nsem > 0 && max_sem == 0.0) || (s_nbvalid > 0 && max_bm == 0.0);
+    const int pool = zero_div ? nsem : ncand;
+    for (int i = tid; i < npad; i += 1024) {
+        SortEntry en;
+        en.key = 0;
+        en.idx = 0xFFFFFFFFu;
+        en.pad = 0;
+        if (i < pool) {
+            double sc;
+            if (zero_div) {
+                sc = c_sem[i];
+            } else {
+                const double sa = (c_fl[i] & 1) ? c_sem[i] / max_sem : 0.0;
+                const double sb = (c_fl[i] & 2) ? c_bm[i] / max_bm : 0.0;
+                sc = __dadd_rn(__dmul_rn(p.wa, sa), __dmul_rn(p.wb, sb));
+                c_sem[i] = sa;
+                c_bm[i] = sb;
+            }
+            c_sc[i] = sc;
+            if (sc == sc) {
+                en.key = f64_ordered(sc);
+                if (en.key == 0) en.key = 1;
+                en.idx = (uint32_t)i;
+                atomicAdd(&s_kept, 1);
+            }
+        }
+        e[i] = en;
+    }
+    sort_entries(e, npad, tid, 1024);
+    const int m = s_kept < p.limit ? s_kept : p.limit;
+    const double hi = m > 0 ? c_sc[e[0].idx] : 0.0, lo = m > 0 ? c_sc[e[m - 1].idx] : 0.0;
+    for (int r = tid; r < m; r += 1024) {
+        const int i = (int)e[r].idx;
+        const double sc = c_sc[i];
+        p.f_rows[r] = c_row[i];
+        p.f_score[r] = sc;
+        p.f_sem[r] = c_sem[i];                      // zero maximum: the raw semantic score
+        p.f_bm[r] = zero_div ? 0.0 : c_bm[i];
+        p.f_flags[r] = zero_div ? 1 : c_fl[i];
+        p.rel[r] = hi > lo ? (sc - lo) / (hi - lo) : 1.0;
+    }
+    if (tid == 0) { *p.n_fused = m; *p.status = zero_div ? 1 : 0; }
+}
+
+static size_t hybrid_fuse_lds(int topn, int nb) {
+    const size_t NC = (size_t)topn + nb;
+    size_t npad = 2;
+    while (npad < NC) npad <<= 1;
+    return npad * sizeof(SortEntry) + NC * (3 * sizeof(double) + sizeof(long long)) + (size_t)nb * 2 * sizeof(int) + NC + 64 + 16;
+}
+
 static thread_local Workspace g_fuse_ws[64];
 
 static int current_device(int* dev) {
@@ -359,6 +665,40 @@ static int run_fuse(int mode, int64_t n, const double* a, const double* b, const
     return RAG_OK;
 }
 
+static size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+static int env_int_m(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+// candidate sets up to this size take the pair-matrix path (three launches); larger ones one launch per round
+static int mmr_sim_limit() {
+    static const int lim = std::min(MMR_SIM_MAX_N, std::max(0, env_int_m("RAG_MMR_SIM_MAX", 512)));
+    return lim;
+}
+
+// enqueue prepare + pair matrix + selection for at most n_max candidates (p.En, p.rel, p.n_dev set by the caller)
+static int enqueue_mmr_sim(const MmrArgs& p, int n_max, double* S, MmrSelArgs sel, hipStream_t s) {
+    MmrState none = {};
+    hipLaunchKernelGGL(mmr_prepare_kernel, dim3((unsigned)n_max), dim3(64), 0, s, p, none);
+    const dim3 grid((n_max + SIM_TC - 1) / SIM_TC, (n_max + SIM_TS - 1) / SIM_TS);
+    hipLaunchKernelGGL(mmr_simmat_kernel, grid, dim3(256), 0, s, p.En, p.n_dev, n_max, p.d, p.metric, S, n_max);
+    sel.S = S;
+    sel.ldS = n_max;
+    sel.rel = p.rel;
+    sel.n_dev = p.n_dev;
+    sel.n_max = n_max;
+    sel.lambda = p.lambda;
+    sel.threshold = p.threshold;
+    sel.max_results = p.max_results;
+    sel.out_idx = p.out_idx;
+    sel.n_out = p.n_out;
+    hipLaunchKernelGGL(mmr_select_kernel, dim3(1), dim3(1024), 0, s, sel);
+    RAG_HIP_CHECK(hipGetLastError());
+    return RAG_OK;
+}
+
 static int run_mmr(int device, int64_t n, int d, const void* emb, int emb_is_f64, const float* X, int ld,
                    const long long* rows_host, const double* rel, double lambda, double thr, int metric, int max_results,
                    int32_t* out_idx, int32_t* n_out) {
@@ -375,19 +715,21 @@ static int run_mmr(int device, int64_t n, int d, const void* emb, int emb_is_f64
     if (prev != device) RAG_HIP_CHECK(hipSetDevice(device));
     struct Restore { int p, d; ~Restore() { if (p != d) (void)hipSetDevice(p); } } restore{prev, device};
     Workspace& ws = g_fuse_ws[device & 63];
+    const bool sim = n <= mmr_sim_limit();
     const size_t esz = emb_is_f64 ? 8 : 4;
-    const size_t eb = X ? (((size_t)n * 8 + 255) & ~(size_t)255) : (((size_t)n * d * esz + 255) & ~(size_t)255);
-    const size_t enb = ((size_t)n * d * 8 + 255) & ~(size_t)255;
-    const size_t rb = ((size_t)n * 8 + 255) & ~(size_t)255;
-    const size_t ob = ((size_t)n * 4 + 255) & ~(size_t)255;
+    const size_t eb = X ? al256((size_t)n * 8) : al256((size_t)n * d * esz);
+    const size_t enb = al256((size_t)n * d * 8);
+    const size_t rb = al256((size_t)n * 8);
+    const size_t ob = al256((size_t)n * 4);
     const int G = (int)((n + MMR_PER_WG - 1) / MMR_PER_WG);
-    const size_t gb = ((size_t)G * 8 + 255) & ~(size_t)255;
-    // [rows or embeddings | En | rel | out_idx | n_out | maxsim | alive | wg_best | wg_bidx | ctrl]
-    if (int rc = ws.ensure(eb + enb + rb + ob + 256 + rb + ob + 2 * gb + 256)) return rc;
+    const size_t gb = al256((size_t)G * 8);
+    const size_t simb = sim ? al256((size_t)n * n * 8) : 0;
+    // [rows or embeddings | En | rel | out_idx | n_out | maxsim | alive | wg_best | wg_bidx | ctrl | pair matrix]
+    if (int rc = ws.ensure(eb + enb + rb + ob + 256 + rb + ob + 2 * gb + 256 + simb)) return rc;
     char* base = static_cast<char*>(ws.ptr);
     hipStream_t s = nullptr;
-    MmrArgs p;
-    p.emb = nullptr; p.X = nullptr; p.rows = nullptr; p.ld = ld; p.emb_is_f64 = emb_is_f64;
+    MmrArgs p = {};
+    p.ld = ld; p.emb_is_f64 = emb_is_f64;
     if (X) {
         RAG_HIP_CHECK(hipMemcpyAsync(base, rows_host, (size_t)n * 8, hipMemcpyHostToDevice, s));
         p.X = X;
@@ -407,17 +749,22 @@ static int run_mmr(int device, int64_t n, int d, const void* emb, int emb_is_f64
     st.wg_best = reinterpret_cast<double*>(sbase + rb + ob);
     st.wg_bidx = reinterpret_cast<int*>(sbase + rb + ob + gb);
     st.ctrl = reinterpret_cast<int*>(sbase + rb + ob + 2 * gb);
+    double* S = reinterpret_cast<double*>(sbase + rb + ob + 2 * gb + 256);
     RAG_HIP_CHECK(hipMemcpyAsync(drel, rel, (size_t)n * 8, hipMemcpyHostToDevice, s));
     RAG_HIP_CHECK(hipMemsetAsync(dn, 0, 256, s));
-    RAG_HIP_CHECK(hipMemsetAsync(st.ctrl, 0, 256, s));
     p.rel = drel; p.lambda = lambda; p.threshold = thr; p.metric = metric; p.n = (int)n; p.d = d;
     p.max_results = max_results; p.out_idx = dout; p.n_out = dn;
-    hipLaunchKernelGGL(mmr_prepare_kernel, dim3((unsigned)n), dim3(64), 0, s, p, st);
-    RAG_HIP_CHECK(hipGetLastError());
-    const int rounds = max_results < (int)n ? max_results : (int)n;
-    for (int r = 0; r < rounds; ++r)
-        hipLaunchKernelGGL(mmr_round_kernel, dim3((unsigned)G), dim3(MMR_WAVES * 64), 0, s, p, st, r);
-    RAG_HIP_CHECK(hipGetLastError());
+    if (sim) {
+        if (int rc = enqueue_mmr_sim(p, (int)n, S, MmrSelArgs{}, s)) return rc;
+    } else {
+        RAG_HIP_CHECK(hipMemsetAsync(st.ctrl, 0, 256, s));
+        hipLaunchKernelGGL(mmr_prepare_kernel, dim3((unsigned)n), dim3(64), 0, s, p, st);
+        RAG_HIP_CHECK(hipGetLastError());
+        const int rounds = max_results < (int)n ? max_results : (int)n;
+        for (int r = 0; r < rounds; ++r)
+            hipLaunchKernelGGL(mmr_round_kernel, dim3((unsigned)G), dim3(MMR_WAVES * 64), 0, s, p, st, r);
+        RAG_HIP_CHECK(hipGetLastError());
+    }
     // [out_idx | n_out] are adjacent in the workspace: one copy, one synchronisation
     std::vector<int32_t> host_out(ob / 4 + 1);
     RAG_HIP_CHECK(hipMemcpyAsync(host_out.data(), dout, ob + sizeof(int), hipMemcpyDeviceToHost, s));
@@ -427,6 +774,121 @@ static int run_mmr(int device, int64_t n, int d, const void* emb, int emb_is_f64
     if (m > 0) memcpy(out_idx, host_out.data(), (size_t)m * sizeof(int32_t));
     *n_out = m;
     return RAG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// search top-N -> hybrid fusion with a keyword list -> MMR -> final hits, enqueued on one stream
+// with no host synchronisation in between (vector_db/search_manager.py:938-970 and :1620-1681).
+int search_device_enqueue(rag_index* h, int64_t nq, const float* q_dev, int k, float min_score, int nprobe,
+                          const uint8_t* row_mask_dev, float* D_dev, int64_t* I_dev, hipStream_t s);     // api.hip
+
+struct HybridPlan {
+    int topn, nb, L, M, d;
+    size_t o_q, o_D, o_I, o_rows, o_bmr, o_bms, o_frows, o_fscore, o_fsem, o_fbm, o_rel, o_fflags, o_En, o_S, o_res, total;
+    // o_res: [out_ids M*8 | out_scores M*8 | picked M*4 | n_out | n_fused | status] in one block
+    size_t res_ids, res_scores, res_picked, res_counts, res_bytes;
+};
+
+static HybridPlan hybrid_plan(const rag_index* h, int topn, int nb, int fuse_limit, int max_results) {
+    HybridPlan p = {};
+    p.topn = topn; p.nb = nb; p.d = h->dim;
+    p.L = std::min(fuse_limit, topn + nb);
+    p.M = std::min(max_results, p.L);
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += al256(bytes); return at; };
+    p.o_q = take((size_t)h->dim * 4);
+    p.o_D = take((size_t)topn * 4);
+    p.o_I = take((size_t)topn * 8);
+    p.o_rows = take((size_t)topn * 8);
+    p.o_bmr = take((size_t)std::max(nb, 1) * 8);
+    p.o_bms = take((size_t)std::max(nb, 1) * 8);
+    p.o_frows = take((size_t)p.L * 8);
+    p.o_fscore = take((size_t)p.L * 8);
+    p.o_fsem = take((size_t)p.L * 8);
+    p.o_fbm = take((size_t)p.L * 8);
+    p.o_rel = take((size_t)p.L * 8);
+    p.o_fflags = take((size_t)p.L);
+    p.o_En = take((size_t)p.L * h->dim * 8);
+    p.o_S = take((size_t)p.L * p.L * 8);
+    p.res_ids = 0;
+    p.res_scores = al256((size_t)p.M * 8);
+    p.res_picked = p.res_scores + al256((size_t)p.M * 8);
+    p.res_counts = p.res_picked + al256((size_t)p.M * 4);
+    p.res_bytes = p.res_counts + 256;
+    p.o_res = take(p.res_bytes);
+    p.total = o;
+    return p;
+}
+
+static int hybrid_check(rag_index* h, int topn, int64_t nb, int fuse_limit, int max_results, int metric, double lambda,
+                        const rag_hybrid_out_t* out) {
+    if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
+    if (!out || !out->ids || !out->scores || !out->n_out) return fail(RAG_ERR_INVALID, "out->ids / scores / n_out are required");
+    if (topn < 1 || topn > HYB_MAX_SEM) return fail(RAG_ERR_INVALID, "topn must be in [1, " + std::to_string(HYB_MAX_SEM) + "]");
+    if (nb < 0 || nb > HYB_MAX_BM) return fail(RAG_ERR_INVALID, "at most " + std::to_string(HYB_MAX_BM) + " keyword hits");
+    if (fuse_limit < 1 || fuse_limit > MMR_SIM_MAX_N) return fail(RAG_ERR_INVALID, "fuse_limit must be in [1, " + std::to_string(MMR_SIM_MAX_N) + "]");
+    if (max_results < 1) return fail(RAG_ERR_INVALID, "max_results must be >= 1");
+    if (metric != RAG_MMR_COSINE && metric != RAG_MMR_DOT && metric != RAG_MMR_EUCLIDEAN) return fail(RAG_ERR_INVALID, "unknown MMR metric");
+    if (!(lambda >= 0.0 && lambda <= 1.0)) return fail(RAG_ERR_INVALID, "lambda must be in [0, 1]");
+    return RAG_OK;
+}
+
+// everything after the staging of inputs; `w` = the plan's workspace, bm lists already at their device addresses
+static int hybrid_enqueue(rag_index* h, const HybridPlan& pl, char* w, const float* q_dev, float min_score, int nprobe,
+                          const uint8_t* mask_dev, const long long* bm_rows_dev, const double* bm_scores_dev, double w_sem,
+                          double w_bm, double lambda, double thr, int metric, const rag_hybrid_out_t& dst, hipStream_t s) {
+    float* D = reinterpret_cast<float*>(w + pl.o_D);
+    int64_t* I = reinterpret_cast<int64_t*>(w + pl.o_I);
+    long long* rows = reinterpret_cast<long long*>(w + pl.o_rows);
+    // 1. semantic top-N; the merge also reports the row position of every hit
+    h->merge_rows_out = rows;
+    const int rc = search_device_enqueue(h, 1, q_dev, pl.topn, min_score, nprobe, mask_dev, D, I, s);
+    h->merge_rows_out = nullptr;
+    if (rc) return rc;
+    if (h->n == 0) RAG_HIP_CHECK(hipMemsetAsync(rows, 0xFF, (size_t)pl.topn * 8, s));     // no hits: every row -1
+    // 2. fusion + relevance normalisation
+    HybridArgs f = {};
+    f.D = D; f.rows = rows; f.topn = pl.topn;
+    f.bm_rows = bm_rows_dev; f.bm_scores = bm_scores_dev; f.nb = pl.nb; f.nrows = h->n;
+    f.wa = w_sem; f.wb = w_bm; f.limit = pl.L;
+    f.f_rows = dst.fused_rows ? reinterpret_cast<long long*>(dst.fused_rows) : reinterpret_cast<long long*>(w + pl.o_frows);
+    f.f_score = dst.fused_scores ? dst.fused_scores : reinterpret_cast<double*>(w + pl.o_fscore);
+    f.f_sem = dst.fused_sem ? dst.fused_sem : reinterpret_cast<double*>(w + pl.o_fsem);
+    f.f_bm = dst.fused_bm ? dst.fused_bm : reinterpret_cast<double*>(w + pl.o_fbm);
+    f.f_flags = reinterpret_cast<unsigned char*>(w + pl.o_fflags);
+    f.rel = reinterpret_cast<double*>(w + pl.o_rel);
+    int* counts = reinterpret_cast<int*>(w + pl.o_res + pl.res_counts);       // [n_out, n_fused, status]
+    f.n_fused = dst.n_fused ? dst.n_fused : counts + 1;
+    f.status = dst.status ? dst.status : counts + 2;
+    const size_t lds = hybrid_fuse_lds(pl.topn, pl.nb);
+    static bool attr_set[64] = {};
+    if (lds > 48 * 1024 && !attr_set[h->device & 63]) {
+        RAG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(hybrid_fuse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[h->device & 63] = true;
+    }
+    hipLaunchKernelGGL(hybrid_fuse_kernel, dim3(1), dim3(1024), lds, s, f);
+    RAG_HIP_CHECK(hipGetLastError());
+    // 3. MMR over the fused candidates, vectors read from the index rows
+    MmrArgs p = {};
+    p.X = h->X;
+    p.rows = f.f_rows;
+    p.pos = h->kind == RAG_KIND_IVF ? h->ivf.pos_dev : nullptr;
+    p.ld = h->ld;
+    p.n_dev = f.n_fused;
+    p.En = reinterpret_cast<double*>(w + pl.o_En);
+    p.rel = f.rel;
+    p.lambda = lambda; p.threshold = thr; p.metric = metric; p.n = pl.L; p.d = h->dim;
+    p.max_results = pl.M;
+    p.out_idx = dst.picked ? dst.picked : reinterpret_cast<int*>(w + pl.o_res + pl.res_picked);
+    p.n_out = dst.n_out;
+    MmrSelArgs sel = {};
+    sel.cand_rows = f.f_rows;
+    sel.cand_score = f.f_score;
+    sel.row_ids = h->ids_dev;
+    sel.id_base = h->id_base;
+    sel.out_ids = reinterpret_cast<long long*>(dst.ids);
+    sel.out_scores = dst.scores;
+    return enqueue_mmr_sim(p, pl.L, reinterpret_cast<double*>(w + pl.o_S), sel, s);
 }
 
 }  // namespace rag
@@ -471,6 +933,97 @@ int rag_mmr_select_rows(rag_index_t* h, int64_t n, const int64_t* rows, const do
     }
     return run_mmr(h->device, n, h->dim, nullptr, 0, h->X, h->ld, where, rel, lambda,
                    similarity_threshold, metric, max_results, out_idx, n_out);
+}
+
+int rag_index_hybrid_mmr_device(rag_index_t* h, const float* q_dev, int topn, float min_score, int nprobe,
+                                const uint8_t* row_mask_dev, int64_t nb, const int64_t* bm25_rows_dev,
+                                const double* bm25_scores_dev, double w_sem, double w_bm25, int fuse_limit, double mmr_lambda,
+                                double mmr_threshold, int mmr_metric, int max_results, const rag_hybrid_out_t* out_dev,
+                                void* stream) {
+    if (int rc = hybrid_check(h, topn, nb, fuse_limit, max_results, mmr_metric, mmr_lambda, out_dev)) return rc;
+    if (!q_dev || (nb > 0 && (!bm25_rows_dev || !bm25_scores_dev))) return fail(RAG_ERR_INVALID, "NULL buffer");
+    if (min_score != min_score) return fail(RAG_ERR_INVALID, "min_score is NaN");
+    RAG_LOCK_INDEX(h);
+    int prev = 0;
+    RAG_HIP_CHECK(hipGetDevice(&prev));
+    if (prev != h->device) RAG_HIP_CHECK(hipSetDevice(h->device));
+    struct Restore { int p, d; ~Restore() { if (p != d) (void)hipSetDevice(p); } } restore{prev, h->device};
+    const HybridPlan pl = hybrid_plan(h, topn, (int)nb, fuse_limit, max_results);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = ws_acquire(h, s)) return rc;
+    if (int rc = h->ws3.ensure(pl.total)) return rc;
+    if (int rc = hybrid_enqueue(h, pl, static_cast<char*>(h->ws3.ptr), q_dev, min_score, nprobe, row_mask_dev,
+                                reinterpret_cast<const long long*>(bm25_rows_dev), bm25_scores_dev, w_sem, w_bm25, mmr_lambda,
+                                mmr_threshold, mmr_metric, *out_dev, s))
+        return rc;
+    return ws_release(h, s);
+}
+
+int rag_index_hybrid_mmr(rag_index_t* h, const float* q, int topn, float min_score, int nprobe, const uint8_t* row_mask,
+                         int64_t nb, const int64_t* bm25_rows, const double* bm25_scores, double w_sem, double w_bm25,
+                         int fuse_limit, double mmr_lambda, double mmr_threshold, int mmr_metric, int max_results,
+                         const rag_hybrid_out_t* out) {
+    if (int rc = hybrid_check(h, topn, nb, fuse_limit, max_results, mmr_metric, mmr_lambda, out)) return rc;
+    if (!q || (nb > 0 && (!bm25_rows || !bm25_scores))) return fail(RAG_ERR_INVALID, "NULL buffer");
+    if (min_score != min_score) return fail(RAG_ERR_INVALID, "min_score is NaN");
+    RAG_LOCK_INDEX(h);
+    int prev = 0;
+    RAG_HIP_CHECK(hipGetDevice(&prev));
+    if (prev != h->device) RAG_HIP_CHECK(hipSetDevice(h->device));
+    struct Restore { int p, d; ~Restore() { if (p != d) (void)hipSetDevice(p); } } restore{prev, h->device};
+    const HybridPlan pl = hybrid_plan(h, topn, (int)nb, fuse_limit, max_results);
+    hipStream_t s = h->stream;
+    if (int rc = ws_acquire(h, s)) return rc;
+    const size_t mb = row_mask ? al256((size_t)h->n) : 0;
+    if (int rc = h->ws3.ensure(pl.total + mb)) return rc;
+    char* w = static_cast<char*>(h->ws3.ptr);
+    float* q_dev = reinterpret_cast<float*>(w + pl.o_q);
+    long long* bmr = reinterpret_cast<long long*>(w + pl.o_bmr);
+    double* bms = reinterpret_cast<double*>(w + pl.o_bms);
+    uint8_t* m_dev = row_mask ? reinterpret_cast<uint8_t*>(w + pl.total) : nullptr;
+    RAG_HIP_CHECK(hipMemcpyAsync(q_dev, q, (size_t)h->dim * 4, hipMemcpyHostToDevice, s));
+    if (nb > 0) {
+        RAG_HIP_CHECK(hipMemcpyAsync(bmr, bm25_rows, (size_t)nb * 8, hipMemcpyHostToDevice, s));
+        RAG_HIP_CHECK(hipMemcpyAsync(bms, bm25_scores, (size_t)nb * 8, hipMemcpyHostToDevice, s));
+    }
+    if (row_mask && h->n > 0) RAG_HIP_CHECK(hipMemcpyAsync(m_dev, row_mask, (size_t)h->n, hipMemcpyHostToDevice, s));
+    // results land in the workspace (one block for the final hits) and are copied out behind the last kernel
+    char* res = w + pl.o_res;
+    rag_hybrid_out_t dst = {};
+    dst.ids = reinterpret_cast<int64_t*>(res + pl.res_ids);
+    dst.scores = reinterpret_cast<double*>(res + pl.res_scores);
+    dst.picked = reinterpret_cast<int32_t*>(res + pl.res_picked);
+    dst.n_out = reinterpret_cast<int32_t*>(res + pl.res_counts);
+    if (int rc = hybrid_enqueue(h, pl, w, q_dev, min_score, nprobe, m_dev, bmr, bms, w_sem, w_bm25, mmr_lambda, mmr_threshold,
+                                mmr_metric, dst, s))
+        return rc;
+    std::vector<unsigned char> host(pl.res_bytes);
+    RAG_HIP_CHECK(hipMemcpyAsync(host.data(), res, pl.res_bytes, hipMemcpyDeviceToHost, s));
+    const bool want_fused = out->fused_rows || out->fused_scores || out->fused_sem || out->fused_bm;
+    std::vector<unsigned char> fused;
+    const size_t fused_bytes = pl.o_rel - pl.o_frows;         // f_rows | f_score | f_sem | f_bm are adjacent
+    if (want_fused) {
+        fused.resize(fused_bytes);
+        RAG_HIP_CHECK(hipMemcpyAsync(fused.data(), w + pl.o_frows, fused_bytes, hipMemcpyDeviceToHost, s));
+    }
+    RAG_HIP_CHECK(hipStreamSynchronize(s));
+    h->ws_pending = false;
+    const int32_t* counts = reinterpret_cast<const int32_t*>(host.data() + pl.res_counts);
+    const int32_t m = counts[0], nf = counts[1], st = counts[2];
+    if (m < 0 || m > pl.M || nf < 0 || nf > pl.L) return fail(RAG_ERR_HIP, "hybrid pipeline returned a bad count");
+    memcpy(out->ids, host.data() + pl.res_ids, (size_t)m * 8);
+    memcpy(out->scores, host.data() + pl.res_scores, (size_t)m * 8);
+    if (out->picked) memcpy(out->picked, host.data() + pl.res_picked, (size_t)m * 4);
+    *out->n_out = m;
+    if (out->n_fused) *out->n_fused = nf;
+    if (out->status) *out->status = st;
+    if (want_fused) {
+        if (out->fused_rows) memcpy(out->fused_rows, fused.data() + (pl.o_frows - pl.o_frows), (size_t)nf * 8);
+        if (out->fused_scores) memcpy(out->fused_scores, fused.data() + (pl.o_fscore - pl.o_frows), (size_t)nf * 8);
+        if (out->fused_sem) memcpy(out->fused_sem, fused.data() + (pl.o_fsem - pl.o_frows), (size_t)nf * 8);
+        if (out->fused_bm) memcpy(out->fused_bm, fused.data() + (pl.o_fbm - pl.o_frows), (size_t)nf * 8);
+    }
+    return RAG_OK;
 }
 
 }  // extern "C"

@@ -613,6 +613,7 @@ __device__ __forceinline__ void finalise_scored(const MergeArgs& a, long long q,
     }
     a.D[(size_t)q * a.k + j] = s;
     a.I[(size_t)q * a.k + j] = id;
+    if (a.rows_out) a.rows_out[(size_t)q * a.k + j] = s < -3.0e38f ? -1 : (long long)key_row(key);
 }
 
 __global__ __launch_bounds__(256) void rescore_select_kernel(RescoreArgs r) {
@@ -901,6 +902,7 @@ int gemm_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float
     m.min_score = min_score;
     m.row_ids = h->ids_dev;
     m.id_base = h->id_base;
+    m.rows_out = h->merge_rows_out;
     m.D = D;
     m.I = I;
 
@@ -1120,6 +1122,7 @@ int ivf_listmajor_scan(rag_index* h, long long nq, const float* qbuf, int k, flo
     m.min_score = min_score;
     m.row_ids = h->ids_dev;
     m.id_base = h->id_base;
+    m.rows_out = h->merge_rows_out;
     m.D = D;
     m.I = I;
     RAG_HIP_CHECK(launch_merge_keys(m, nq, s));
@@ -1268,6 +1271,7 @@ int prefilter_scan_search(rag_index* h, const float* qbuf, int k, float min_scor
     fin.min_score = min_score;
     fin.row_ids = h->ids_dev;
     fin.id_base = h->id_base;
+    fin.rows_out = h->merge_rows_out;
     fin.D = D;
     fin.I = I;
     VerifyArgs v = {};

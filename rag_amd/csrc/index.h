@@ -56,6 +56,8 @@ struct IvfState {
     long long* list_begin_dev = nullptr;  // [nlist + 1]
     long long* orig_dev = nullptr;        // [n_packed]
     long long orig_cap = 0;
+    long long* pos_dev = nullptr;         // [n_packed] insertion position -> storage position
+    long long pos_cap = 0;
     Workspace ws;                         // coarse results, packed mask
 };
 
@@ -86,6 +88,8 @@ struct rag_index {
     int* xb_maxnorm = nullptr;      // device: bit pattern of the largest row norm converted so far
     rag::Workspace ws;              // queries, partial keys, staging
     rag::Workspace ws2;             // combined masks, host-API result staging
+    rag::Workspace ws3;             // search -> fusion -> MMR pipeline: candidate lists, fp64 rows, pair matrix
+    long long* merge_rows_out = nullptr;   // while set, the final merge of a search also writes every hit's row position here
     hipStream_t stream = nullptr;   // used by the host-pointer entry points
     hipEvent_t ws_event = nullptr;  // end of the last work that used ws / ws2
     hipStream_t ws_stream = nullptr;

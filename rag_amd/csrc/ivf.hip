@@ -78,6 +78,7 @@ void ivf_free(rag_index* h) {
     if (v.quantizer) rag_index_free(v.quantizer);
     if (v.list_begin_dev) (void)hipFree(v.list_begin_dev);
     if (v.orig_dev) (void)hipFree(v.orig_dev);
+    if (v.pos_dev) (void)hipFree(v.pos_dev);
     v.ws.release();
     v = IvfState();
 }
@@ -150,6 +151,12 @@ static int ivf_repack(rag_index* h) {
         RAG_HIP_CHECK(hipMalloc((void**)&v.orig_dev, (size_t)v.orig_cap * sizeof(long long)));
     }
     RAG_HIP_CHECK(hipMemcpy(v.orig_dev, v.orig.data(), (size_t)n * sizeof(long long), hipMemcpyHostToDevice));
+    if (v.pos_cap < n) {
+        if (v.pos_dev) (void)hipFree(v.pos_dev);
+        v.pos_cap = std::max(n, v.pos_cap + v.pos_cap / 2);
+        RAG_HIP_CHECK(hipMalloc((void**)&v.pos_dev, (size_t)v.pos_cap * sizeof(long long)));
+    }
+    RAG_HIP_CHECK(hipMemcpy(v.pos_dev, v.pos.data(), (size_t)n * sizeof(long long), hipMemcpyHostToDevice));
     RAG_HIP_CHECK(hipMemcpy(v.list_begin_dev, begin.data(), ((size_t)v.nlist + 1) * sizeof(long long), hipMemcpyHostToDevice));
     v.n_packed = n;
     return RAG_OK;
@@ -235,6 +242,7 @@ int ivf_search_device(rag_index* h, long long nq, const float* qbuf, int k, floa
         m.min_score = min_score;
         m.row_ids = h->ids_dev;
         m.id_base = h->id_base;
+    m.rows_out = h->merge_rows_out;
         m.slot_ids = nullptr;
         m.slot_stride = 0;
         m.D = D + (size_t)q0 * k;

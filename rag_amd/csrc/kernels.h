@@ -49,6 +49,7 @@ struct MergeArgs {
     const int* run_if;           // when not NULL the merge runs only if *run_if != 0
     float* D;                    // [nq][k]
     long long* I;                // [nq][k]
+    long long* rows_out;         // nullptr or [nq][k]: row position of every hit (-1 where I is -1)
 };
 
 int scan_rows_per_tile(int d4);

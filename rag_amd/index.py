@@ -264,6 +264,101 @@ class DeviceIndex:
         return D, I
 
 
+_MMR_METRICS = {"cosine": _lib.MMR_COSINE, "dot_product": _lib.MMR_DOT, "euclidean": _lib.MMR_EUCLIDEAN}
+
+
+def hybrid_mmr(index: "DeviceIndex", q, topn: int, bm25_rows, bm25_scores, *, fuse_limit: Optional[int] = None,
+               max_results: int = 10, semantic_weight: float = 0.65, bm25_weight: float = 0.35,
+               mmr_lambda: float = 0.6, mmr_threshold: float = 0.8, mmr_metric: str = "cosine",
+               min_score: Optional[float] = None, nprobe: int = 1, row_mask=None, want_fused: bool = False):
+    """Search top-``topn`` -> hybrid fusion with the keyword hits ``(bm25_rows, bm25_scores)`` (row
+    positions, BM25 scores) -> MMR -> ``max_results`` hits, as ONE call into the library
+    (vector_db/search_manager.py:938-970 and :1620-1681).
+
+    numpy inputs: returns a dict with ``ids``, ``scores`` (fused), ``picked`` (positions in the
+    fused list), ``status`` (1 = a zero maximum, the reference's fall-back to the semantic list)
+    and, with ``want_fused``, ``fused_rows / fused_scores / fused_sem / fused_bm``.
+    CUDA-tensor query (bm25 lists as CUDA tensors too): nothing is synchronised; the dict holds
+    CUDA tensors plus ``n_out`` / ``n_fused`` / ``status`` as one-element tensors."""
+    topn = int(topn)
+    if fuse_limit is None:
+        fuse_limit = min(1024, topn + len(bm25_rows))
+    fuse_limit = int(fuse_limit)
+    ms = -FLT_MAX if min_score is None else float(min_score)
+    metric = _MMR_METRICS.get(mmr_metric, _lib.MMR_COSINE)
+    out = _lib.HybridOut()
+    if _is_torch_cuda(q):
+        import torch
+        q = q.reshape(-1).contiguous()
+        if q.dtype != torch.float32 or q.numel() != index.dim:
+            raise ValueError(f"expected a float32 query of {index.dim} elements")
+        dev = q.device
+        bmr = bm25_rows.to(device=dev, dtype=torch.int64).contiguous()
+        bms = bm25_scores.to(device=dev, dtype=torch.float64).contiguous()
+        nb = bmr.numel()
+        res = {"ids": torch.empty(max_results, dtype=torch.int64, device=dev),
+               "scores": torch.empty(max_results, dtype=torch.float64, device=dev),
+               "picked": torch.empty(max_results, dtype=torch.int32, device=dev),
+               "n_out": torch.zeros(1, dtype=torch.int32, device=dev),
+               "n_fused": torch.zeros(1, dtype=torch.int32, device=dev),
+               "status": torch.zeros(1, dtype=torch.int32, device=dev)}
+        if want_fused:
+            res["fused_rows"] = torch.empty(fuse_limit, dtype=torch.int64, device=dev)
+            for name in ("fused_scores", "fused_sem", "fused_bm"):
+                res[name] = torch.empty(fuse_limit, dtype=torch.float64, device=dev)
+        for name, t in res.items():
+            setattr(out, name, t.data_ptr())
+        m_ptr = None
+        if row_mask is not None:
+            if not _is_torch_cuda(row_mask) or row_mask.dtype != torch.uint8 or row_mask.numel() != len(index):
+                raise ValueError("row_mask must be a CUDA uint8 tensor with one byte per row")
+            row_mask = row_mask.contiguous()
+            m_ptr = C.c_void_p(row_mask.data_ptr())
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        check(lib.rag_index_hybrid_mmr_device(index._h, C.c_void_p(q.data_ptr()), topn, ms, int(nprobe), m_ptr, nb,
+                                              C.c_void_p(bmr.data_ptr()) if nb else None,
+                                              C.c_void_p(bms.data_ptr()) if nb else None,
+                                              float(semantic_weight), float(bm25_weight), fuse_limit, float(mmr_lambda),
+                                              float(mmr_threshold), metric, int(max_results), C.byref(out),
+                                              C.c_void_p(stream)))
+        res["_keepalive"] = (q, bmr, bms, row_mask)
+        return res
+    q = np.ascontiguousarray(q, dtype=np.float32).reshape(-1)
+    if q.size != index.dim:
+        raise ValueError(f"expected a query of {index.dim} elements")
+    bmr = np.ascontiguousarray(bm25_rows, dtype=np.int64).reshape(-1)
+    bms = np.ascontiguousarray(bm25_scores, dtype=np.float64).reshape(-1)
+    if bmr.size != bms.size:
+        raise ValueError("one BM25 score per row")
+    m = None
+    if row_mask is not None:
+        m = np.ascontiguousarray(row_mask, dtype=np.uint8).reshape(-1)
+        if m.size != len(index):
+            raise ValueError("row_mask must have one byte per row")
+    ids = np.empty(max_results, dtype=np.int64)
+    scores = np.empty(max_results, dtype=np.float64)
+    picked = np.empty(max_results, dtype=np.int32)
+    counts = np.zeros(3, dtype=np.int32)
+    out.ids, out.scores, out.picked = ids.ctypes.data, scores.ctypes.data, picked.ctypes.data
+    out.n_out, out.n_fused, out.status = counts.ctypes.data, counts.ctypes.data + 4, counts.ctypes.data + 8
+    fused = {}
+    if want_fused:
+        fused["fused_rows"] = np.empty(fuse_limit, dtype=np.int64)
+        for name in ("fused_scores", "fused_sem", "fused_bm"):
+            fused[name] = np.empty(fuse_limit, dtype=np.float64)
+        for name, a in fused.items():
+            setattr(out, name, a.ctypes.data)
+    check(lib.rag_index_hybrid_mmr(index._h, _ptr(q), topn, ms, int(nprobe), _ptr(m), bmr.size,
+                                   _ptr(bmr) if bmr.size else None, _ptr(bms) if bms.size else None,
+                                   float(semantic_weight), float(bm25_weight), fuse_limit, float(mmr_lambda),
+                                   float(mmr_threshold), metric, int(max_results), C.byref(out)))
+    n_out, n_fused, status = (int(c) for c in counts)
+    res = {"ids": ids[:n_out], "scores": scores[:n_out], "picked": picked[:n_out], "status": status, "n_fused": n_fused}
+    for name, a in fused.items():
+        res[name] = a[:n_fused]
+    return res
+
+
 def merge_topk_strided(nlists: int, nq: int, k: int, d_ptr: int, d_stride: int, i_ptr: int, i_stride: int, device):
     """Merge `nlists` result sets that sit at d_ptr + g*d_stride floats / i_ptr +
     g*i_stride int64s in device memory (e.g. the slots of an all-gather buffer)."""
