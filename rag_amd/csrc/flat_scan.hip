@@ -367,12 +367,38 @@ __global__ __launch_bounds__(1024) void merge_keys_kernel(MergeArgs a) {
     // it matter: each thread walks its runs from the head and stops at the first key below.
     const long long P = a.per_query / k;
     if (a.fast_cap > 0 && P >= k && P <= cap && P * k == a.per_query) {
-        const int n2 = pow2_ceil((int)P);
-        for (int i = tid; i < n2; i += 1024) buf[i] = i < P ? in[(size_t)i * k] : KEY_EMPTY;
-        if (tid == 0) *s_cnt = 0;
-        bitonic_sort_desc_lds(buf, n2, tid, 1024, SyncBlock());
-        const u64 bound = buf[k - 1];
+        // both selections are done by counting, not sorting: keys are distinct (the row sits in the low
+        // bits), so "the number of keys above mine" is a rank, and a count over an LDS array read by
+        // every lane at the same address (a broadcast) needs no barrier between its steps
+        const int Pn = (int)P;
+        // a lower bound of the answer's k-th key from the run heads: deal the heads into k groups; the
+        // group maxima are k distinct keys, so their minimum has k keys at or above it
+        u64* gmax = cand;                                   // [k], before cand is filled
+        for (int i = tid; i < k; i += 1024) gmax[i] = KEY_EMPTY;
+        if (tid == 0) { *s_cnt = 0; *s_thr = ~0ull; }
         __syncthreads();
+        for (int i = tid; i < Pn; i += 1024) {
+            const u64 hd = in[(size_t)i * k];
+            buf[i] = hd;
+            atomicMax(&gmax[i % k], hd);
+        }
+        __syncthreads();
+        for (int i = tid; i < k; i += 1024) atomicMin(s_thr, gmax[i]);
+        __syncthreads();
+        if (*s_thr == KEY_EMPTY) {
+            // a group without a key (masked or short row ranges): the exact k-th largest head instead
+            __syncthreads();
+            for (int i = tid; i < Pn; i += 1024) {
+                const u64 mine = buf[i];
+                if (mine == KEY_EMPTY) continue;
+                int above = 0;
+#pragma unroll 8
+                for (int j = 0; j < Pn; ++j) above += buf[j] > mine ? 1 : 0;
+                if (above == k - 1) *s_thr = mine;
+            }
+            __syncthreads();
+        }
+        const u64 bound = *s_thr;
         if (bound != KEY_EMPTY) {
             for (long long p = tid; p < P; p += 1024) {
                 for (int j = 0; j < k; ++j) {
@@ -383,16 +409,19 @@ __global__ __launch_bounds__(1024) void merge_keys_kernel(MergeArgs a) {
                 }
             }
             __syncthreads();
-            const int c = *s_cnt;
+            const int c = *s_cnt;                        // c >= k: k run heads reach the bound
             if (c <= a.fast_cap) {
-                const int c2 = pow2_ceil(c);
-                for (int i = c + tid; i < c2; i += 1024) cand[i] = KEY_EMPTY;
-                bitonic_sort_desc_lds(cand, c2, tid, 1024, SyncBlock());
-                for (int j = tid; j < k; j += 1024) finalise_hit(a, q, j, cand[j]);     // c >= k here
+                for (int i = tid; i < c; i += 1024) {
+                    const u64 mine = cand[i];
+                    int above = 0;
+#pragma unroll 8
+                    for (int j = 0; j < c; ++j) above += cand[j] > mine ? 1 : 0;
+                    if (above < k) finalise_hit(a, q, above, mine);
+                }
                 return;
             }
         }
-        __syncthreads();      // too many keys tie near the bound: stream everything instead
+        __syncthreads();      // fewer than k non-empty runs, or too many keys tie near the bound: stream everything
     }
 
     for (int i = tid; i < cap; i += 1024) buf[i] = KEY_EMPTY;

@@ -300,6 +300,11 @@ int ivf_reconstruct_rows(rag_index* h, long long n, const int64_t* rows, std::ve
 // selected last) and an argmax over the workgroup.
 constexpr int MMR_SIM_MAX_N = 1024;
 constexpr int SIM_TC = 8, SIM_TS = 8;      // candidates x selected rows per workgroup
+// JL = ceil(d / 64) doubles of a row per lane, compile time (0: any d, rows re-read per pair).  The wave's two candidate rows
+// sit in registers and every selected row's loads are independent of the arithmetic, so the eight
+// rows of the tile stream through without a dependent-load chain.  Lanes past d hold zeros, which
+// leave an fma chain unchanged.
+template <int JL>
 __global__ __launch_bounds__(256) void mmr_simmat_kernel(const double* En, const int* n_dev, int n_max, int d, int metric,
                                                          double* S, int ldS) {
     const int n = n_dev ? *n_dev : n_max;
@@ -310,33 +315,76 @@ __global__ __launch_bounds__(256) void mmr_simmat_kernel(const double* En, const
     const int c1 = c0 + 1 < n ? c0 + 1 : c0;
     const double* e0 = En + (size_t)c0 * d;
     const double* e1 = En + (size_t)c1 * d;
-    for (int si = 0; si < SIM_TS; ++si) {
-        const int sr = s0 + si;
-        if (sr >= n) break;
-        const double* es = En + (size_t)sr * d;
-        double a0 = 0.0, a1 = 0.0;
-        if (metric == RAG_MMR_EUCLIDEAN) {
-#pragma unroll 4
-            for (int j = lane; j < d; j += 64) {
-                const double e = es[j];
-                const double f0 = e0[j] - e, f1 = e1[j] - e;
-                a0 = fma(f0, f0, a0);
-                a1 = fma(f1, f1, a1);
+    if constexpr (JL > 0) {
+        double r0[JL], r1[JL];
+#pragma unroll
+        for (int t = 0; t < JL; ++t) {
+            const int j = lane + 64 * t;
+            r0[t] = j < d ? e0[j] : 0.0;
+            r1[t] = j < d ? e1[j] : 0.0;
+        }
+#pragma unroll 2
+        for (int si = 0; si < SIM_TS; ++si) {
+            const int sr = s0 + si < n ? s0 + si : n - 1;          // past the end: recompute the last row (not stored)
+            const double* es = En + (size_t)sr * d;
+            double e[JL];
+#pragma unroll
+            for (int t = 0; t < JL; ++t) {
+                const int j = lane + 64 * t;
+                e[t] = j < d ? es[j] : 0.0;
             }
-        } else {
-#pragma unroll 4
-            for (int j = lane; j < d; j += 64) {
-                const double e = es[j];
-                a0 = fma(e0[j], e, a0);
-                a1 = fma(e1[j], e, a1);
+            double a0 = 0.0, a1 = 0.0;
+            if (metric == RAG_MMR_EUCLIDEAN) {
+#pragma unroll
+                for (int t = 0; t < JL; ++t) {
+                    const double f0 = r0[t] - e[t], f1 = r1[t] - e[t];
+                    a0 = fma(f0, f0, a0);
+                    a1 = fma(f1, f1, a1);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < JL; ++t) {
+                    a0 = fma(r0[t], e[t], a0);
+                    a1 = fma(r1[t], e[t], a1);
+                }
+            }
+            a0 = wave_sum_f64(a0);
+            a1 = wave_sum_f64(a1);
+            if (metric == RAG_MMR_EUCLIDEAN) { a0 = 1.0 / (1.0 + sqrt(a0)); a1 = 1.0 / (1.0 + sqrt(a1)); }
+            if (lane == 0 && s0 + si < n) {
+                S[(size_t)c0 * ldS + sr] = a0;
+                if (c0 + 1 < n) S[(size_t)(c0 + 1) * ldS + sr] = a1;
             }
         }
-        a0 = wave_sum_f64(a0);
-        a1 = wave_sum_f64(a1);
-        if (metric == RAG_MMR_EUCLIDEAN) { a0 = 1.0 / (1.0 + sqrt(a0)); a1 = 1.0 / (1.0 + sqrt(a1)); }
-        if (lane == 0) {
-            S[(size_t)c0 * ldS + sr] = a0;
-            if (c0 + 1 < n) S[(size_t)(c0 + 1) * ldS + sr] = a1;
+    } else {
+        for (int si = 0; si < SIM_TS; ++si) {
+            const int sr = s0 + si;
+            if (sr >= n) break;
+            const double* es = En + (size_t)sr * d;
+            double a0 = 0.0, a1 = 0.0;
+            if (metric == RAG_MMR_EUCLIDEAN) {
+#pragma unroll 4
+                for (int j = lane; j < d; j += 64) {
+                    const double e = es[j];
+                    const double f0 = e0[j] - e, f1 = e1[j] - e;
+                    a0 = fma(f0, f0, a0);
+                    a1 = fma(f1, f1, a1);
+                }
+            } else {
+#pragma unroll 4
+                for (int j = lane; j < d; j += 64) {
+                    const double e = es[j];
+                    a0 = fma(e0[j], e, a0);
+                    a1 = fma(e1[j], e, a1);
+                }
+            }
+            a0 = wave_sum_f64(a0);
+            a1 = wave_sum_f64(a1);
+            if (metric == RAG_MMR_EUCLIDEAN) { a0 = 1.0 / (1.0 + sqrt(a0)); a1 = 1.0 / (1.0 + sqrt(a1)); }
+            if (lane == 0) {
+                S[(size_t)c0 * ldS + sr] = a0;
+                if (c0 + 1 < n) S[(size_t)(c0 + 1) * ldS + sr] = a1;
+            }
         }
     }
 }
@@ -471,9 +519,12 @@ __global__ __launch_bounds__(1024) void hybrid_fuse_kernel(HybridArgs p) {
     double* c_bm = c_sem + NC;                                                     // [NC]
     double* c_sc = c_bm + NC;                                                      // [NC]
     long long* c_row = reinterpret_cast<long long*>(c_sc + NC);                    // [NC]
-    int* bm_first = reinterpret_cast<int*>(c_row + NC);                            // [nb] first valid appearance and keyword-only
-    int* bm_match = bm_first + p.nb;                                               // [nb] semantic hit with the same row, or -1
-    unsigned char* c_fl = reinterpret_cast<unsigned char*>(bm_match + p.nb);       // [NC]
+    long long* b_row = c_row + NC;                                                 // [nb] keyword rows (-1: ignored)
+    int* bm_first = reinterpret_cast<int*>(b_row + p.nb);                          // [nb]
+    int* bm_last = bm_first + p.nb;                                                // [nb]
+    int* bm_match = bm_last + p.nb;                                                // [nb]
+    int* bm_before = bm_match + p.nb;                                              // [nb]
+    unsigned char* c_fl = reinterpret_cast<unsigned char*>(bm_before + p.nb);      // [NC]
     if (tid == 0) { s_nsem = 0; s_nbvalid = 0; s_nonly = 0; s_kept = 0; s_maxsem = 0ull; s_maxbm = 0ull; }
     __syncthreads();
     // semantic side
@@ -481,48 +532,59 @@ __global__ __launch_bounds__(1024) void hybrid_fuse_kernel(HybridArgs p) {
         const long long r = p.rows[i];
         c_fl[i] = 0;
         c_bm[i] = 0.0;
+        c_row[i] = r;
         if (r >= 0) {
             const double sv = (double)p.D[i];
-            c_row[i] = r;
             c_sem[i] = sv;
             c_fl[i] = 1;
             atomicAdd(&s_nsem, 1);
             atomicMax(&s_maxsem, f64_ordered(sv));
         }
     }
-    __syncthreads();
-    const int nsem = s_nsem;
-    // keyword side: validity, duplicates (the later score wins, the first appearance keeps the place)
+    // keyword side: rows into LDS (an ignored row becomes -1), maxima over every valid entry.
+    // bm_first[j] = lowest j2 with the same row, bm_last[j] = highest, bm_match[j] = lowest semantic hit with it
     for (int j = tid; j < p.nb; j += 1024) {
-        const long long r = p.bm_rows[j];
-        int first = 0, match = -1;
+        long long r = p.bm_rows[j];
         if (r >= 0 && r < p.nrows) {
             atomicAdd(&s_nbvalid, 1);
             atomicMax(&s_maxbm, f64_ordered(p.bm_scores[j]));
-            first = 1;
-            for (int j2 = 0; j2 < j; ++j2)
-                if (p.bm_rows[j2] == r) { first = 0; break; }
-            if (first) {
-                for (int i = 0; i < nsem; ++i)
-                    if (p.rows[i] == r) { match = i; break; }
-            }
+        } else {
+            r = -1;
         }
-        bm_first[j] = first;
-        bm_match[j] = match;
+        b_row[j] = r;
+        bm_first[j] = j;
+        bm_last[j] = j;
+        bm_match[j] = 0x7FFFFFFF;
+        bm_before[j] = 0;
+    }
+    __syncthreads();
+    const int nsem = s_nsem;
+    // every (keyword hit, keyword hit) and (keyword hit, semantic hit) pair, dealt over the workgroup
+    for (int t = tid; t < p.nb * p.nb; t += 1024) {
+        const int j = t / p.nb, j2 = t % p.nb;
+        if (j2 != j && b_row[j] >= 0 && b_row[j2] == b_row[j]) {
+            if (j2 < j) atomicMin(&bm_first[j], j2);
+            else atomicMax(&bm_last[j], j2);
+        }
+    }
+    for (int t = tid; t < p.nb * nsem; t += 1024) {
+        const int j = t / nsem, i = t % nsem;
+        if (b_row[j] >= 0 && c_row[i] == b_row[j]) atomicMin(&bm_match[j], i);
+    }
+    __syncthreads();
+    // keyword-only rows keep the order of their first appearance: place = keyword-only firsts before j
+    for (int t = tid; t < p.nb * p.nb; t += 1024) {
+        const int j = t / p.nb, j2 = t % p.nb;
+        if (j2 < j && b_row[j2] >= 0 && bm_first[j2] == j2 && bm_match[j2] == 0x7FFFFFFF) atomicAdd(&bm_before[j], 1);
     }
     __syncthreads();
     for (int j = tid; j < p.nb; j += 1024) {
-        if (!bm_first[j]) continue;
-        const long long r = p.bm_rows[j];
-        double val = p.bm_scores[j];
-        for (int j2 = j + 1; j2 < p.nb; ++j2)
-            if (p.bm_rows[j2] == r) val = p.bm_scores[j2];
+        if (b_row[j] < 0 || bm_first[j] != j) continue;
+        const double val = p.bm_scores[bm_last[j]];          // a repeated row keeps the later score
         int slot = bm_match[j];
-        if (slot < 0) {
-            int before = 0;
-            for (int j2 = 0; j2 < j; ++j2) before += (bm_first[j2] && bm_match[j2] < 0) ? 1 : 0;
-            slot = nsem + before;
-            c_row[slot] = r;
+        if (slot == 0x7FFFFFFF) {
+            slot = nsem + bm_before[j];
+            c_row[slot] = b_row[j];
             c_sem[slot] = 0.0;
             c_fl[slot] = 0;
             atomicAdd(&s_nonly, 1);
@@ -583,7 +645,7 @@ static size_t hybrid_fuse_lds(int topn, int nb) {
     const size_t NC = (size_t)topn + nb;
     size_t npad = 2;
     while (npad < NC) npad <<= 1;
-    return npad * sizeof(SortEntry) + NC * (3 * sizeof(double) + sizeof(long long)) + (size_t)nb * 2 * sizeof(int) + NC + 64 + 16;
+    return npad * sizeof(SortEntry) + NC * (3 * sizeof(double) + sizeof(long long)) + (size_t)nb * (4 * sizeof(int) + sizeof(long long)) + NC + 64 + 16;
 }
 
 static thread_local Workspace g_fuse_ws[64];
@@ -683,7 +745,12 @@ static int enqueue_mmr_sim(const MmrArgs& p, int n_max, double* S, MmrSelArgs se
     MmrState none = {};
     hipLaunchKernelGGL(mmr_prepare_kernel, dim3((unsigned)n_max), dim3(64), 0, s, p, none);
     const dim3 grid((n_max + SIM_TC - 1) / SIM_TC, (n_max + SIM_TS - 1) / SIM_TS);
-    hipLaunchKernelGGL(mmr_simmat_kernel, grid, dim3(256), 0, s, p.En, p.n_dev, n_max, p.d, p.metric, S, n_max);
+    const int jl = (p.d + 63) / 64;
+    if (jl <= 4) hipLaunchKernelGGL(mmr_simmat_kernel<4>, grid, dim3(256), 0, s, p.En, p.n_dev, n_max, p.d, p.metric, S, n_max);
+    else if (jl <= 8) hipLaunchKernelGGL(mmr_simmat_kernel<8>, grid, dim3(256), 0, s, p.En, p.n_dev, n_max, p.d, p.metric, S, n_max);
+    else if (jl <= 12) hipLaunchKernelGGL(mmr_simmat_kernel<12>, grid, dim3(256), 0, s, p.En, p.n_dev, n_max, p.d, p.metric, S, n_max);
+    else if (jl <= 16) hipLaunchKernelGGL(mmr_simmat_kernel<16>, grid, dim3(256), 0, s, p.En, p.n_dev, n_max, p.d, p.metric, S, n_max);
+    else hipLaunchKernelGGL(mmr_simmat_kernel<0>, grid, dim3(256), 0, s, p.En, p.n_dev, n_max, p.d, p.metric, S, n_max);
     sel.S = S;
     sel.ldS = n_max;
     sel.rel = p.rel;

@@ -14,6 +14,7 @@
 // position (row_alias), so ids, masks, ties and results are the same as for a flat
 // index of the same rows.
 #include <float.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -54,8 +55,10 @@ constexpr long long IVF_QCHUNK = 32768;     // queries per launch (grid.y) and w
 static long long ivf_slices(const rag_index* h, long long nq, int nprobe) {
     const int tile = scan_rows_per_tile(h->ld / 4);
     const long long avg_tiles = std::max<long long>(1, (h->n / std::max(1, h->ivf.nlist)) / tile);
-    long long slices = 2048 / std::max<long long>(1, nq * nprobe);
-    slices = std::min<long long>(slices, std::max<long long>(1, avg_tiles / 32));
+    static const int slice_tiles = std::max(1, getenv("RAG_IVF_SLICE_TILES") ? atoi(getenv("RAG_IVF_SLICE_TILES")) : 32);   // measurement knob
+    static const int max_blocks = std::max(64, getenv("RAG_IVF_SCAN_BLOCKS") ? atoi(getenv("RAG_IVF_SCAN_BLOCKS")) : 2048);
+    long long slices = max_blocks / std::max<long long>(1, nq * nprobe);
+    slices = std::min<long long>(slices, std::max<long long>(1, avg_tiles / slice_tiles));
     return slices < 1 ? 1 : slices;
 }
 

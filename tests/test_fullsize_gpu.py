@@ -31,6 +31,18 @@ def corpus():
     planted = rng.choice(N, 64, replace=False)
     planted[0], planted[1] = 0, N - 1                      # first and last row
     X[torch.from_numpy(planted).to(dev)] = Q                # row planted[i] == query i
+    # near-duplicate clusters around queries 50..52 (for the fusion + MMR pipeline: candidates whose
+    # mutual similarity exceeds the MMR threshold, so the penalty branch decides the selection)
+    g = torch.Generator(device=dev)
+    g.manual_seed(77)
+    for qi in (50, 51, 52):
+        for count, off in ((40, 0.2), (40, 0.3), (40, 0.4)):
+            # a cluster centre at cosine ~ 1/sqrt(1 + off^2) from the query, members at cosine ~ 0.92 from each other
+            centre = Q[qi] + off / D ** 0.5 * torch.randn((D,), generator=g, device=dev)
+            rows = torch.from_numpy(rng.choice(N, count, replace=False)).to(dev)
+            dup = centre[None, :] + 0.3 / D ** 0.5 * torch.randn((count, D), generator=g, device=dev)
+            X[rows] = dup / dup.norm(dim=1, keepdim=True)
+    X[torch.from_numpy(planted).to(dev)] = Q                # (a cluster row may have landed on a planted one)
     idx = DeviceIndex(D, metric="ip")
     idx.adopt(X)
     yield torch, X, Q, idx, planted
@@ -157,3 +169,42 @@ def test_bf16_first_pass_returns_the_fp32_answer(corpus):
             assert np.allclose(Dp.cpu().numpy(), Ds.cpu().numpy(), rtol=1e-5, atol=1e-6)
     finally:
         idx.set_prefilter(False)
+
+
+def test_hybrid_fusion_mmr_pipeline_at_full_size(corpus):
+    """Configuration 'hybrid semantic + BM25 fusion + MMR (lambda 0.5) re-rank of top-200 to top-10,
+    10M x 768' through the one-call pipeline: fused list and selection equal the oracle's
+    (oracle.fusion + oracle.mmr) given the semantic stage's scores, on queries surrounded by
+    near-duplicate clusters so that the MMR penalty branch changes the outcome."""
+    torch, X, Q, idx, planted = corpus
+    from oracle import fusion as of
+    from oracle import mmr as om
+    from rag_amd.index import hybrid_mmr
+    rng = np.random.default_rng(21)
+    fired = 0
+    for qi in (50, 51, 52, 3):
+        q = Q[qi].cpu().numpy()
+        Dq, Iq = idx.search(Q[qi:qi + 1], 200)
+        Dn, In = Dq.cpu().numpy()[0], Iq.cpu().numpy()[0]
+        assert np.allclose(Dn, _rescore(torch, X, Q[qi:qi + 1], Iq.cpu())[0], rtol=1e-5, atol=1e-6)
+        bm_rows = np.concatenate([rng.choice(In, 50, replace=False), rng.integers(0, N, 50)])
+        bm_scores = rng.uniform(0.0, 1.0, 100)
+        got = hybrid_mmr(idx, q, 200, bm_rows, bm_scores, max_results=10, mmr_lambda=0.5, mmr_threshold=0.8,
+                         mmr_metric="cosine", want_fused=True)
+        ranked = of.hybrid_rank([(int(r), float(s)) for s, r in zip(Dn, In)],
+                                [(int(r), float(s)) for r, s in zip(bm_rows, bm_scores)], 250)
+        f_rows = [t[0] for t in ranked]
+        f_scores = [t[1] for t in ranked]
+        assert got["status"] == 0 and got["fused_rows"].tolist() == f_rows
+        assert np.array_equal(got["fused_scores"], np.array(f_scores))
+        E = X[torch.tensor(f_rows, device=X.device)].cpu().numpy().astype(np.float64)
+        picked = om.mmr_select_fast(E, f_scores, 0.5, 10, 0.8, "cosine")
+        assert got["picked"].tolist() == picked
+        assert got["ids"].tolist() == [f_rows[p] for p in picked]
+        fired += picked != list(range(10))
+        # and the device variant leaves the same answer without a host round trip
+        dev = hybrid_mmr(idx, Q[qi], 200, torch.from_numpy(bm_rows).cuda(), torch.from_numpy(bm_scores).cuda(),
+                         max_results=10, mmr_lambda=0.5, mmr_threshold=0.8)
+        torch.cuda.synchronize()
+        assert dev["ids"].cpu().numpy().tolist() == got["ids"].tolist()
+    assert fired >= 3            # the clustered queries: diversification changed the top 10
