@@ -45,8 +45,10 @@ def test_random_configurations(seed):
         idx.close()
 
 
-@pytest.mark.parametrize("seed", range(5))
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 345])
 def test_random_ivf_configurations(seed):
+    """Seed 345 holds a row whose two best centroid scores lie 9e-9 apart (its list differs between
+    summation orders): the comparison excuses exactly such rows and nothing else."""
     from oracle import flat, ivf
     from rag_amd import DeviceIndex
     rng = np.random.default_rng(2000 + seed)
@@ -68,7 +70,8 @@ def test_random_ivf_configurations(seed):
         idx.search(Q[:1], 1, nprobe=nprobe)                    # packs the first part
         idx.add(X[cut:])
         D, I = idx.search(Q, k, nprobe=nprobe, row_mask=mask)
-        Dr, Ir = ivf.ivf_search(X, C, Q, k, nprobe, row_mask=mask)
-        bad = flat.compare_topk(D, I, Dr, Ir, rtol=RTOL, atol=ATOL)
+        bad, excused, amb = ivf.ivf_check(D, I, X, C, Q, k, nprobe, row_mask=mask, rtol=RTOL, atol=ATOL)
+        if amb:
+            print(f"seed {seed}: {amb} queries differ through coarse ties, {excused} rows excused")
         assert bad == [], (dict(n=n, d=d, nlist=nlist, nprobe=nprobe, nq=nq, k=k, path=idx.last_path), bad[:3])
         idx.close()

@@ -1,5 +1,7 @@
 """IVF (coarse assignment + list scan on the GPU) against the CPU oracle with the
-same centroids.  Tolerance as for the exhaustive search."""
+same centroids.  Tolerance as for the exhaustive search; a difference is excused only where it
+hinges on a coarse tie within that tolerance (oracle.ivf.ivf_check), and the excused rows are
+counted and printed.  FAISS is not installed: parity unpinned vs FAISS IndexIVFFlat itself."""
 import numpy as np
 import pytest
 
@@ -19,6 +21,14 @@ def _cmp(D, I, Dr, Ir):
     assert bad == [], bad[:5]
 
 
+def _check_ivf(D, I, X, C, Q, k, nprobe, **kw):
+    from oracle import ivf
+    bad, excused, amb = ivf.ivf_check(D, I, X, C, Q, k, nprobe, rtol=RTOL, atol=ATOL, **kw)
+    if amb:
+        print(f"ivf_check: {amb} queries differ from the oracle through coarse ties, {excused} rows excused")
+    assert bad == [], bad[:5]
+
+
 @pytest.mark.parametrize("n,d,nlist,nprobe,nq,k", [
     (60_000, 128, 64, 8, 1, 10), (60_000, 128, 64, 8, 40, 10), (30_000, 768, 128, 16, 3, 10),
     (20_000, 384, 32, 32, 5, 100), (5_000, 100, 16, 4, 2, 10), (80_000, 64, 256, 64, 200, 5),
@@ -34,13 +44,13 @@ def test_ivf_matches_oracle(n, d, nlist, nprobe, nq, k):
     idx.train_ivf(nlist, centroids=C)
     idx.add(X[: n // 3])
     D0, I0 = idx.search(Q, k, nprobe=nprobe)                 # search between adds forces a re-pack
-    _cmp(D0, I0, *ivf.ivf_search(X[: n // 3], C, Q, k, nprobe))
+    _check_ivf(D0, I0, X[: n // 3], C, Q, k, nprobe)
     idx.add(X[n // 3:])
     D, I = idx.search(Q, k, nprobe=nprobe)
     # batches in which lists are probed by several queries take the list-major MFMA scan
     listmajor = nq * nprobe >= nlist and k <= 64 and d % 32 == 0
     assert idx.last_path == ("ivf-listmajor" if listmajor else "ivf")
-    _cmp(D, I, *ivf.ivf_search(X, C, Q, k, nprobe))
+    _check_ivf(D, I, X, C, Q, k, nprobe)
     # nprobe = nlist degenerates to the exhaustive answer
     from oracle import flat
     D, I = idx.search(Q, k, nprobe=nlist)
@@ -63,14 +73,14 @@ def test_ivf_mask_ids_reconstruct_soft_delete():
     idx.train_ivf(nlist, sample=X)                   # first nlist sample rows become the centroids
     idx.add(X, ids=ids)
     D, I = idx.search(Q, 10, nprobe=7)
-    _cmp(D, I, *ivf.ivf_search(X, C, Q, 10, 7, ids=ids))
+    _check_ivf(D, I, X, C, Q, 10, 7, ids=ids)
     mask = (rng.uniform(size=n) < 0.4).astype(np.uint8)
     D, I = idx.search(Q, 10, nprobe=7, row_mask=mask, min_score=0.02)
-    _cmp(D, I, *ivf.ivf_search(X, C, Q, 10, 7, ids=ids, row_mask=mask, min_score=0.02))
+    _check_ivf(D, I, X, C, Q, 10, 7, ids=ids, row_mask=mask, min_score=0.02)
     Qb = _unit(rng, 300, d)                           # a batch large enough for the list-major scan
     D, I = idx.search(Qb, 10, nprobe=7, row_mask=mask, min_score=0.02)
     assert idx.last_path == "ivf-listmajor"
-    _cmp(D, I, *ivf.ivf_search(X, C, Qb, 10, 7, ids=ids, row_mask=mask, min_score=0.02))
+    _check_ivf(D, I, X, C, Qb, 10, 7, ids=ids, row_mask=mask, min_score=0.02)
     R = idx.reconstruct([0, 123, n - 1])
     assert np.array_equal(R, X[[0, 123, n - 1]])
     gone = np.arange(0, n, 3)
@@ -78,7 +88,7 @@ def test_ivf_mask_ids_reconstruct_soft_delete():
     m2 = np.ones(n, np.uint8)
     m2[gone] = 0
     D, I = idx.search(Q, 10, nprobe=7)
-    _cmp(D, I, *ivf.ivf_search(X, C, Q, 10, 7, ids=ids, row_mask=m2))
+    _check_ivf(D, I, X, C, Q, 10, 7, ids=ids, row_mask=m2)
     idx.close()
 
 
