@@ -553,6 +553,16 @@ def main(argv=None):
         kb_ms = kmsb / max(nsteps, 1)                     # dominant-kernel time per step
         ach_tf = flops / (kb_ms * 1e-3) / 1e12 if kmsb > 0 else 0.0
         ach_gbs = (hi - lo) * bytes_per_row / (kb_ms * 1e-3) / 1e9 if kmsb > 0 else 0.0
+        if pathb == "narrow":
+            # up to 32 queries: one pass over the corpus, HBM-bound (the events bracket the sample launch,
+            # its merge and the main launch, so every row is inside)
+            return {"value": B * nsteps / dtb, "unit": "queries/sec", "batch": B, "steps": nsteps,
+                    "ms_per_step": dtb / nsteps * 1e3, "path": pathb,
+                    "roofline": {"bound": "hbm", "kernel": "narrow_topk_kernel", "achieved": ach_gbs, "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
+                                 "kernel_ms_per_step": kb_ms, "launches": launchesb,
+                                 "algorithmic_bytes_per_launch": (hi - lo) * bytes_per_row,
+                                 "mfma_TFLOPs": ach_tf, "mfma_frac_of_fp32_peak": ach_tf / peak_tflops}}
         return {"value": B * nsteps / dtb, "unit": "queries/sec", "batch": B, "steps": nsteps,
                 "ms_per_step": dtb / nsteps * 1e3, "path": pathb,
                 "roofline": {"bound": "mfma", "achieved": ach_tf,
@@ -567,8 +577,11 @@ def main(argv=None):
     big = mid = None
     if not args.no_big:
         big = batch_leg(args.big_batch, args.big_steps or min(args.steps, 5))
+    mid16 = None
     if args.mid_batch > 0:
         mid = batch_leg(min(args.mid_batch, args.big_batch), min(args.steps, 20))
+        if args.mid_batch > 16:
+            mid16 = batch_leg(16, min(args.steps, 20))
     # opt-in mode, reported beside the fp32 numbers and never as `value`: bf16 first pass on the
     # matrix cores + fp32 re-scoring of the rows within the error margin (same answers)
     pre = pre1 = pre_mid = None
@@ -632,6 +645,8 @@ def main(argv=None):
             out["batch_%d" % args.big_batch] = big
         if mid is not None:
             out["batch_%d" % mid["batch"]] = mid
+        if mid16 is not None:
+            out["batch_16"] = mid16
         if pre is not None:
             out["batch_%d_bf16_first_pass" % args.big_batch] = pre
         if pre_mid is not None:

@@ -172,6 +172,10 @@ size_t prefilter_scan_workspace(const rag_index* h, int k);
 int prefilter_scan_search(rag_index* h, const float* qbuf, int k, float min_score, const uint8_t* mask,
                           float* D, long long* I, hipStream_t s);
 size_t gemm_topk_workspace(const rag_index* h, long long nq, int k);
+bool narrow_topk_supported(const rag_index* h, long long nq, int k);          // narrow_topk.hip
+size_t narrow_topk_workspace(const rag_index* h, long long nq, int k);
+int narrow_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask,
+                       float* D, long long* I, hipStream_t s);
 int ivf_reconstruct_rows(rag_index* h, long long n, const int64_t* rows, std::vector<long long>& storage_rows);
 
 static int env_int(const char* name, int dflt) {
@@ -271,7 +275,11 @@ static int flat_scan_search(rag_index* h, long long nq, const float* qbuf, int k
 }
 
 // bytes the exhaustive search needs in h->ws after the padded queries
+// 5..32 queries without the bf16 first pass: the register-streaming kernel (one corpus pass at the HBM rate)
+static bool use_narrow(const rag_index* h, long long nq, int k) { return !h->prefilter && narrow_topk_supported(h, nq, k); }
+
 size_t flat_search_workspace(const rag_index* h, long long nq, int k) {
+    if (use_narrow(h, nq, k)) return narrow_topk_workspace(h, nq, k);
     if (gemm_topk_supported(h, nq, k)) return gemm_topk_workspace(h, nq, k);
     if (prefilter_scan_supported(h, nq, k)) return prefilter_scan_workspace(h, k);
     return (size_t)((k > 64) ? 1 : 8) * scan_blocks(h, k) * 4 * k * sizeof(u64);
@@ -284,6 +292,7 @@ int flat_search_prepared(rag_index* h, long long nq, const float* qbuf, int k, f
                          float* D, long long* I, hipStream_t s) {
     const size_t qbytes = ((size_t)nq * h->ld * sizeof(float) + 255) & ~(size_t)255;
     if (int rc = h->ws.ensure(qbytes + flat_search_workspace(h, nq, k))) return rc;
+    if (use_narrow(h, nq, k)) return narrow_topk_search(h, nq, qbuf, k, min_score, mask, D, I, s);
     if (gemm_topk_supported(h, nq, k)) return gemm_topk_search(h, nq, qbuf, k, min_score, mask, D, I, s);
     if (prefilter_scan_supported(h, nq, k)) return prefilter_scan_search(h, qbuf, k, min_score, mask, D, I, s);
     return flat_scan_search(h, nq, qbuf, k, min_score, mask, D, I, s);

@@ -360,7 +360,7 @@ __global__ __launch_bounds__(1024) void merge_keys_kernel(MergeArgs a) {
     u64* cand = buf + cap + 2;                            // [MERGE_FAST_CAP] fast path only
     const long long q = blockIdx.x;
     if (a.run_if && *a.run_if == 0) return;
-    const u64* in = a.keys + (size_t)q * a.per_query;
+    const u64* in = a.keys + (size_t)q * (a.stride ? a.stride : a.per_query);
 
     // ---- fast path: the input is P descending runs of k keys.  The k-th largest run head is a
     // lower bound of the answer's k-th key (k different keys reach it), and only keys at or above
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(1024) void merge_keys_small_kernel(MergeArgs a) {
     const int nw = blockDim.x >> 6;
     const int k = a.k;
     const long long q = blockIdx.x;
-    const u64* in = a.keys + (size_t)q * a.per_query;
+    const u64* in = a.keys + (size_t)q * (a.stride ? a.stride : a.per_query);
     u64 list = KEY_EMPTY, thr = KEY_EMPTY;
     // a wave's chunks of 64 keys are requested MU at a time before the first is looked at: the
     // keys sit in L2 / HBM, and one dependent load per chunk made the latency of every chunk the

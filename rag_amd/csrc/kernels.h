@@ -38,6 +38,7 @@ struct ScanArgs {
 struct MergeArgs {
     const u64* keys;             // [nq][per_query], descending runs of k keys (one per producer)
     long long per_query;
+    long long stride;            // keys of query q start at q * stride (0: q * per_query)
     int k;
     int cap;                     // LDS buffer capacity (power of two, >= 2k, >= 2048)
     int fast_cap;                // set by the launcher: candidate slots of the run-head fast path (0 = off)

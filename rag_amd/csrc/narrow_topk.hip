@@ -1,0 +1,500 @@
+// Small batches (5..32 queries): one pass over the corpus at the HBM rate, scored on the fp32
+// matrix cores and fused with top-k selection (gfx950).
+//
+// Roofline: HBM.  Every corpus row is read once per launch: algorithmic bytes = n * ld * 4.  The
+// arithmetic (2 * nq * n * ld flops on v_mfma_f32_16x16x4_f32) needs 40 % (<= 16 queries) or 80 %
+// (<= 32) of the time the bytes need at the HBM peak, so the kernel is built around keeping loads
+// in flight, not around the MFMA issue rate.
+//
+// Structure.  The whole query block lives in LDS for the life of the workgroup (<= 32 x ld fp32,
+// 96 KiB at ld = 768), laid out in MFMA fragment order.  Each wave streams its own contiguous row
+// range with coalesced loads -- one wave instruction fetches 8 rows x 128 contiguous bytes -- into a
+// ring of registers that keeps (NSETS - 1) * DEPTH steps of 32 rows x 32 floats (24 KiB per wave) in
+// flight.  A landed step is turned into MFMA A fragments through a wave-private 4 KiB LDS image
+// (ds_write_b128 rows, ds_read_b128 fragments, 16-byte chunks XOR-swizzled by row pair so both
+// are conflict free): lane (i = lane & 15, kq = lane >> 4) receives k = 16 m + 4 kq + v of row i.
+// (Loading the fragments straight from global memory -- 16 rows x 64 bytes per instruction -- caps
+// the kernel at 5.35 TB/s; the same bytes as 1 KiB-contiguous loads run at 6.95 TB/s.)  The LDS
+// image of the queries is stored in the k order the fragments have, so a lane's B fragment is one
+// ds_read_b128 at a lane-linear address.  Waves never synchronise with each other after the query
+// block is staged: no barrier in the K loop or between tiles; LDS operations of one wave complete
+// in issue order, which is all the transposer needs.
+//
+// Selection (k <= 32).  Per wave and query a candidate buffer of 64 keys in global memory (L2) and
+// a threshold in LDS.  After a 32-row tile a lane compares its 2 x NJ x 4 scores with its query's
+// threshold (and with the best k-th score any wave has published, shared through an atomicMax
+// word per query); hits are rare after warm-up.  A buffer holding more than 32 keys is sorted in
+// registers (one key per lane, bitonic across the wave), cut to k, and the threshold tightened.
+// At the end every wave writes its k best keys per query and merge_keys_*_kernel reduces them.
+//
+// Scores are a k-ordered fp32 fma chain per (row, query), independent of the launch geometry.
+#include <float.h>
+
+#include <algorithm>
+
+#include "index.h"
+#include "topk_keys.h"
+
+namespace rag {
+
+int merge_cap(long long per_query, int k);
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f4acc __attribute__((ext_vector_type(4)));
+
+constexpr int NR_WAVES = 8;            // waves per workgroup (2 per SIMD), one workgroup per CU
+constexpr int NR_TILE = 32;            // corpus rows per wave step (two 16-row MFMA row groups)
+constexpr int NR_TRIG = 32;            // compact a candidate buffer once it holds more keys than this
+constexpr int NR_CAP = NR_TRIG + NR_TILE;   // 64: one key per lane when sorted
+constexpr int NR_MAX_K = 32;
+
+// timing-only ablations for diagnostic builds (outputs are wrong when non-zero): bit 0 skips the tile epilogue,
+// bit 1 loads the same bytes as 1 KiB contiguous per wave instruction (what the access pattern costs)
+#ifndef RAG_NARROW_DIAG
+#define RAG_NARROW_DIAG 0
+#endif
+
+struct NarrowArgs {
+    const float* X;
+    const float* Q;            // [nq][ld] padded queries
+    const uint8_t* mask;       // nullptr or n bytes
+    u64* cand;                 // [waves][NJ*16][NR_CAP]
+    u64* part;                 // [nq][waves][k]
+    unsigned int* gthr;        // [nq] best published k-th score (ordered-float bits, 0 = none)
+    const int* run_if;
+    const float* thr_init;     // nullptr or [nq][k] best-first scores of a sample of OTHER, lower-numbered rows: entry k-1
+                               // bounds the answer's k-th score from below (-FLT_MAX: fewer than k in the sample)
+    long long row_begin;       // this launch scans rows [row_begin, row_end), row_begin a multiple of 32
+    long long row_end;
+    int wave_base;             // this launch's waves write runs wave_base .. of the W_total runs per query in part
+    int W_total;
+    int nq;
+    int ld;                    // floats per row, multiple of 128
+    int k;
+};
+
+// one K step (32 floats) of a 32-row tile as loaded: [row group][8-row half], 16 bytes per lane each
+// (lane = 8 * row + chunk: 8 rows x 128 contiguous bytes per wave instruction)
+struct AChunk {
+    f4 r[2][2];
+};
+
+// NSETS register sets of DEPTH chunks each rotate through the roles "being multiplied" and "in flight":
+// while one set feeds the MFMAs, the loads of the next NSETS - 1 groups are outstanding.  The number of
+// groups per row (ld / (16 * DEPTH)) is a multiple of NSETS, so every tile starts with the same rotation.
+template <int NJ, int DEPTH, int NSETS>
+__global__ __launch_bounds__(NR_WAVES * 64, 2) void narrow_topk_kernel(NarrowArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (a.run_if && *a.run_if == 0) return;
+    constexpr int NQB = NJ * 16;                        // queries of the block
+    const int G = a.ld / 16;                            // K chunks per row
+    f4* Qs = reinterpret_cast<f4*>(smem);               // [G][NJ][64] fragment order
+    f4* stage = Qs + (size_t)G * NJ * 64;               // [waves][2 row groups][16 rows][8] transposer images (4 KiB per wave)
+    float* s_thr = reinterpret_cast<float*>(stage + NR_WAVES * 256);     // [waves][NQB]
+    int* s_cnt = reinterpret_cast<int*>(s_thr + NR_WAVES * NQB);         // [waves][NQB]
+    int* s_flag = s_cnt + NR_WAVES * NQB;                                // [waves]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int k = a.k;
+    const int ld4 = a.ld / 4;
+    const f4* X4 = reinterpret_cast<const f4*>(a.X);
+    const f4* Q4 = reinterpret_cast<const f4*>(a.Q);
+
+    // ---- stage the query block in fragment order -------------------------------------------
+    // Qs[(g * NJ + nj) * 64 + kq * 16 + c] = Q[nj * 16 + c][16 g + 4 kq .. + 3]
+    for (int i = tid; i < G * NJ * 64; i += NR_WAVES * 64) {
+        const int c = i & 15, q4 = (i >> 4) & 3, gn = i >> 6;
+        const int nj = gn % NJ, g = gn / NJ;
+        int q = nj * 16 + c;
+        q = q < a.nq ? q : a.nq - 1;                    // surplus columns repeat the last query; never selected
+        Qs[i] = Q4[(size_t)q * ld4 + g * 4 + q4];
+    }
+    for (int i = tid; i < NR_WAVES * NQB; i += NR_WAVES * 64) {
+        float t_init = -INFINITY;
+        const int q = i % NQB;
+        if (a.thr_init && q < a.nq) {
+            // a row of this launch that only ties the sample's k-th score loses to k lower-numbered rows
+            const float v = a.thr_init[(size_t)q * a.k + a.k - 1];
+            if (v > -FLT_MAX) t_init = v;
+        }
+        s_thr[i] = t_init;
+        s_cnt[i] = 0;
+    }
+    if (tid < NR_WAVES) s_flag[tid] = 0;
+    __syncthreads();
+
+    // ---- this wave's rows: a contiguous range of 32-row tiles --------------------------------
+    const long long W = (long long)gridDim.x * NR_WAVES;
+    const long long w = (long long)blockIdx.x * NR_WAVES + wave;
+    const long long T = (a.row_end - a.row_begin + NR_TILE - 1) / NR_TILE;
+    const long long t0 = T * w / W, t1 = T * (w + 1) / W;
+    float* my_thr = s_thr + wave * NQB;
+    int* my_cnt = s_cnt + wave * NQB;
+    u64* my_cand = a.cand + (size_t)w * NQB * NR_CAP;
+    // the wave's transposer: [row group][16 rows][8 chunks of 16 bytes], chunk c of row r at position c ^ ((r >> 1) & 7)
+    f4* tp = stage + (size_t)wave * 256;
+    const int lrow = lane >> 3, lchunk = lane & 7;      // as loaded: row within an 8-row half, 16-byte chunk
+    int wr_off[2], rd_off[2];                           // f4 units inside one row group's image
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int ru = hh * 8 + lrow;
+        wr_off[hh] = ru * 8 + (lchunk ^ ((ru >> 1) & 7));
+        rd_off[hh] = r16 * 8 + ((4 * hh + kq) ^ ((r16 >> 1) & 7));      // hh = which 16 floats of the step (m)
+    }
+
+    if (t0 < t1) {
+        // address of this lane's 16 bytes in step 0 of tile t: row group rg, 8-row half hh (rows past the end
+        // repeat the last row; tiles past the wave's range repeat its last tile: loaded, never used)
+        auto row_ptr = [&](long long t, int rg, int hh) {
+            t = t < t1 ? t : t1 - 1;
+            long long row = a.row_begin + t * NR_TILE + rg * 16 + hh * 8 + lrow;
+            row = row < a.row_end ? row : a.row_end - 1;
+            return X4 + row * ld4 + lchunk;
+        };
+        AChunk ring[NSETS][DEPTH];
+        const int steps = a.ld / 32;                    // K steps per tile
+        const int groups = steps / DEPTH;               // a multiple of NSETS
+        // the loader runs NSETS - 1 groups ahead of the MFMAs: (lt, lg) = tile and group it loads next
+        long long lt = t0;
+        int lg = 0;
+        const f4* lp[2][2];
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) lp[rg][hh] = row_ptr(lt, rg, hh);
+        auto issue = [&](AChunk (&set)[DEPTH]) {
+#pragma unroll
+            for (int j = 0; j < DEPTH; ++j)
+#pragma unroll
+                for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh)
+                        set[j].r[rg][hh] = __builtin_nontemporal_load(lp[rg][hh] + (lg * DEPTH + j) * 8);
+            if (++lg == groups) {
+                lg = 0;
+                ++lt;
+#pragma unroll
+                for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) lp[rg][hh] = row_ptr(lt, rg, hh);
+            }
+        };
+#pragma unroll
+        for (int sset = 0; sset < NSETS - 1; ++sset) issue(ring[sset]);
+        // the transposer and the query fragments run one K step ahead of the MFMAs: while a step multiplies,
+        // the next step's rows go through LDS (written, then read back as fragments; one wave's LDS
+        // operations complete in issue order, so the image can be reused at once)
+        f4 af[2][2][2], bq[2][2][NJ];                   // [parity][row group][m], [parity][m][query column]
+        auto transpose = [&](const AChunk& c, int par) {
+#pragma unroll
+            for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) tp[rg * 128 + wr_off[hh]] = c.r[rg][hh];
+#pragma unroll
+            for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) af[par][rg][m] = tp[rg * 128 + rd_off[m]];
+        };
+        auto read_queries = [&](int step, int par) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int nj = 0; nj < NJ; ++nj) bq[par][m][nj] = Qs[((size_t)(2 * step + m) * NJ + nj) * 64 + lane];
+        };
+        transpose(ring[0][0], 0);
+        read_queries(0, 0);
+        for (long long t = t0; t < t1; ++t) {
+            f4acc acc[2][NJ];
+#pragma unroll
+            for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                for (int nj = 0; nj < NJ; ++nj) acc[rg][nj] = (f4acc){0.f, 0.f, 0.f, 0.f};
+            // the other waves' progress on this lane's queries: requested now, looked at after the tile
+            unsigned int tg_bits[NJ];
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj) {
+                const int q = nj * 16 + r16;
+                tg_bits[nj] = __hip_atomic_load(&a.gthr[q < a.nq ? q : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            for (int gg = 0; gg < groups; gg += NSETS) {
+#pragma unroll
+                for (int sset = 0; sset < NSETS; ++sset) {
+                    // the set that was multiplied last is free: the group NSETS - 1 ahead goes there
+                    issue(ring[(sset + NSETS - 1) % NSETS]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < DEPTH; ++j) {
+                        const int par = (sset * DEPTH + j) & 1;          // NSETS * DEPTH is even: the parity repeats per iteration
+                        const int step = (gg + sset) * DEPTH + j;
+                        // next step (of this tile, or step 0 of the next one: the ring holds it already)
+                        const int nstep = step + 1 < steps ? step + 1 : 0;
+                        if (j + 1 < DEPTH) transpose(ring[sset][j + 1], par ^ 1);
+                        else transpose(ring[(sset + 1) % NSETS][0], par ^ 1);
+                        read_queries(nstep, par ^ 1);
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+#pragma unroll
+                            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                                for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                                    for (int nj = 0; nj < NJ; ++nj)
+                                        acc[rg][nj] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[par][rg][m][v], bq[par][m][nj][v], acc[rg][nj], 0, 0, 0);
+                    }
+                }
+            }
+            float tg[NJ];
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj) tg[nj] = tg_bits[nj] != 0u ? ordered_f32(tg_bits[nj]) : -INFINITY;
+            if (RAG_NARROW_DIAG & 1) {
+                float keep = tg[0];
+#pragma unroll
+                for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                    for (int nj = 0; nj < NJ; ++nj) keep += acc[rg][nj][0] + acc[rg][nj][1] + acc[rg][nj][2] + acc[rg][nj][3];
+                if (keep == 123.456f) my_thr[0] = keep;      // keeps the accumulators live
+                continue;
+            }
+
+            // ---- tile epilogue: lane (c = r16, kq) holds rows 4 kq .. 4 kq + 3 of each row group for query nj * 16 + c
+            const long long row_base = a.row_begin + t * NR_TILE + kq * 4;
+            // sort every buffer holding more than min_count keys, keep its k best, tighten the threshold
+            auto compact = [&](int min_count) {
+                // the pushed keys are re-read through memory by other lanes of this wave: drain the stores first
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                for (int q = 0; q < NQB && q < a.nq; ++q) {
+                    const int c = my_cnt[q];                     // wave-uniform
+                    if (c <= min_count) continue;
+                    u64 key = lane < c ? my_cand[(size_t)q * NR_CAP + lane] : KEY_EMPTY;
+                    key = wave_sort_desc(key, lane);             // empty slots (masked rows, rows past the end) sort last
+                    const int keep = c < k ? c : k;
+                    if (lane < keep) my_cand[(size_t)q * NR_CAP + lane] = key;
+                    const u64 kth = readlane_u64(key, k - 1);
+                    if (c >= k && kth != KEY_EMPTY) {
+                        const float t_new = key_score(kth);
+                        if (lane == 0) {
+                            my_thr[q] = t_new;
+                            atomicMax(&a.gthr[q], f32_ordered(t_new));
+                        }
+                    }
+                    if (lane == 0) my_cnt[q] = keep;
+                }
+                if (lane == 0) s_flag[wave] = 0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            };
+            if (t == t0 && !a.thr_init) {
+                // the wave's first tile with no threshold to start from: every row is a candidate, so the 32 keys
+                // of a query go straight to their slots (row position in the tile), no counting
+#pragma unroll
+                for (int nj = 0; nj < NJ; ++nj) {
+                    const int q = nj * 16 + r16;
+#pragma unroll
+                    for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            const long long row = row_base + rg * 16 + reg;
+                            const bool ok = q < a.nq && row < a.row_end && (!a.mask || a.mask[row]);
+                            my_cand[(size_t)q * NR_CAP + rg * 16 + kq * 4 + reg] = ok ? make_key(acc[rg][nj][reg], (uint32_t)row) : KEY_EMPTY;
+                        }
+                }
+                if (lane < NQB) my_cnt[lane] = NR_TILE;
+                SyncWave()();
+                if (t + 1 < t1) compact(k - 1);                  // a threshold for the tiles that follow
+                continue;
+            }
+            float thr[NJ];
+            bool any = false;
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj) {
+                const int q = nj * 16 + r16;
+                thr[nj] = q < a.nq ? my_thr[q] : INFINITY;
+#pragma unroll
+                for (int rg = 0; rg < 2; ++rg) {
+                    const float m = fmaxf(fmaxf(acc[rg][nj][0], acc[rg][nj][1]), fmaxf(acc[rg][nj][2], acc[rg][nj][3]));
+                    any |= m > thr[nj] && m >= tg[nj];          // a tie with another wave's k-th best may still win on row number
+                }
+            }
+            if (__ballot(any) != 0ull) {
+#pragma unroll
+                for (int nj = 0; nj < NJ; ++nj) {
+                    const int q = nj * 16 + r16;
+#pragma unroll
+                    for (int rg = 0; rg < 2; ++rg) {
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            const float sc = acc[rg][nj][reg];
+                            const long long row = row_base + rg * 16 + reg;
+                            if (sc > thr[nj] && sc >= tg[nj] && row < a.row_end && (!a.mask || a.mask[row])) {
+                                const int pos = atomicAdd(&my_cnt[q], 1);
+                                my_cand[(size_t)q * NR_CAP + pos] = make_key(sc, (uint32_t)row);
+                                if (pos + 1 > NR_TRIG) s_flag[wave] = 1;
+                            }
+                        }
+                    }
+                }
+                SyncWave()();                                    // the lanes' LDS updates, in order, before the flag is read
+                if (s_flag[wave] != 0) compact(NR_TRIG);
+            }
+        }
+    }
+
+    // ---- every query's k best keys of this wave ------------------------------------------------
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (int q = 0; q < NQB && q < a.nq; ++q) {
+        const int c = my_cnt[q];
+        u64 key = lane < c ? my_cand[(size_t)q * NR_CAP + lane] : KEY_EMPTY;
+        key = wave_sort_desc(key, lane);
+        if (lane < k) a.part[((size_t)q * a.W_total + a.wave_base + w) * k + lane] = key;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+static int env_int_n(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+static size_t narrow_lds_bytes(int ld, int nj) {
+    return (size_t)ld * nj * 16 * sizeof(float) + (size_t)NR_WAVES * 4096 + (size_t)NR_WAVES * nj * 16 * 8 + NR_WAVES * 4 + 16;
+}
+
+static int narrow_grid(long long rows) {
+    static const int grid_env = env_int_n("RAG_NARROW_WGS", 0);          // measurement only
+    int grid = grid_env > 0 ? grid_env : 256;
+    // a wave should have at least two tiles to walk
+    const long long tiles = (rows + NR_TILE - 1) / NR_TILE;
+    const long long max_grid = std::max<long long>(1, tiles / (2 * NR_WAVES));
+    if (grid > max_grid) grid = (int)max_grid;
+    return grid;
+}
+
+// On a long corpus a first, short launch over the leading rows gives every query a threshold (the k-th
+// best score of 32768 rows) before the main launch starts: each wave of the main launch sees only a few
+// thousand rows, and with nothing but its own rows to go by nearly every tile would hold candidates.
+constexpr long long NR_SAMPLE_ROWS = 32768;     // one 32-row tile for each of 1024 waves
+struct NarrowPlan {
+    long long sample;          // rows of the first launch (0: single launch)
+    int grid_s, grid_m;
+    long long Ws, Wm;
+    size_t cand_bytes, part_bytes, tmp_bytes;
+};
+static NarrowPlan narrow_plan(const rag_index* h, long long nq, int k) {
+    static const int sample_on = env_int_n("RAG_NARROW_SAMPLE", 1);     // measurement only
+    NarrowPlan p = {};
+    p.sample = (sample_on && h->n >= 32 * NR_SAMPLE_ROWS) ? NR_SAMPLE_ROWS : 0;
+    p.grid_s = p.sample ? (int)(p.sample / (NR_TILE * NR_WAVES)) : 0;
+    p.grid_m = narrow_grid(h->n - p.sample);
+    p.Ws = (long long)p.grid_s * NR_WAVES;
+    p.Wm = (long long)p.grid_m * NR_WAVES;
+    const int nqb = nq <= 16 ? 16 : 32;
+    p.cand_bytes = ((size_t)std::max(p.Ws, p.Wm) * nqb * NR_CAP * sizeof(u64) + 255) & ~(size_t)255;
+    p.part_bytes = ((size_t)nq * (p.Ws + p.Wm) * k * sizeof(u64) + 255) & ~(size_t)255;
+    p.tmp_bytes = p.sample ? ((((size_t)nq * k * 12) + 255) & ~(size_t)255) + 256 : 0;
+    return p;
+}
+
+bool narrow_topk_supported(const rag_index* h, long long nq, int k) {
+    static const int on = env_int_n("RAG_NARROW_DIRECT", 1);
+    static const int min_nq = env_int_n("RAG_GEMM_MIN_NQ", 5);
+    if (!on || h->kind != RAG_KIND_FLAT || nq < min_nq || nq > 32 || k > NR_MAX_K || h->n < 4096) return false;
+    if ((h->ld % 128) != 0) return false;
+    return narrow_lds_bytes(h->ld, nq <= 16 ? 1 : 2) <= 160 * 1024;
+}
+
+size_t narrow_topk_workspace(const rag_index* h, long long nq, int k) {
+    const NarrowPlan p = narrow_plan(h, nq, k);
+    return p.cand_bytes + p.part_bytes + p.tmp_bytes + 256;
+}
+
+template <int NJ, int DEPTH, int NSETS>
+static int launch_narrow(const NarrowArgs& a, int grid, size_t lds, int device, hipStream_t s) {
+    static bool attr_set[64] = {};
+    if (!attr_set[device & 63]) {
+        RAG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(narrow_topk_kernel<NJ, DEPTH, NSETS>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[device & 63] = true;
+    }
+    hipLaunchKernelGGL((narrow_topk_kernel<NJ, DEPTH, NSETS>), dim3(grid), dim3(NR_WAVES * 64), lds, s, a);
+    RAG_HIP_CHECK(hipGetLastError());
+    return RAG_OK;
+}
+
+static int launch_narrow_shape(const NarrowArgs& a, int nj, int grid, size_t lds, int device, hipStream_t s) {
+    // 4 register sets of 2 K steps where a row holds a multiple of 8 steps (ld % 256 == 0), of 1 step otherwise
+    const bool wide = (a.ld % 256) == 0;
+    if (nj == 1) return wide ? launch_narrow<1, 2, 4>(a, grid, lds, device, s) : launch_narrow<1, 1, 4>(a, grid, lds, device, s);
+    return wide ? launch_narrow<2, 2, 4>(a, grid, lds, device, s) : launch_narrow<2, 1, 4>(a, grid, lds, device, s);
+}
+
+// qbuf: padded queries; the caller has sized h->ws with narrow_topk_workspace() behind them
+int narrow_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask,
+                       float* D, long long* I, hipStream_t s) {
+    const NarrowPlan p = narrow_plan(h, nq, k);
+    const int nj = nq <= 16 ? 1 : 2;
+    const size_t qbytes = ((size_t)nq * h->ld * sizeof(float) + 255) & ~(size_t)255;
+    if (h->ws.bytes < qbytes + narrow_topk_workspace(h, nq, k))
+        return fail(RAG_ERR_INVALID, "internal: workspace not sized for the narrow path");
+    char* w = static_cast<char*>(h->ws.ptr) + qbytes;
+    NarrowArgs a = {};
+    a.X = h->X;
+    a.Q = qbuf;
+    a.mask = mask;
+    a.cand = reinterpret_cast<u64*>(w);
+    a.part = reinterpret_cast<u64*>(w + p.cand_bytes);
+    float* tmpD = reinterpret_cast<float*>(w + p.cand_bytes + p.part_bytes);
+    long long* tmpI = reinterpret_cast<long long*>(w + p.cand_bytes + p.part_bytes + ((((size_t)nq * k * 4) + 255) & ~(size_t)255));
+    a.gthr = reinterpret_cast<unsigned int*>(w + p.cand_bytes + p.part_bytes + p.tmp_bytes);
+    a.W_total = (int)(p.Ws + p.Wm);
+    a.nq = (int)nq;
+    a.ld = h->ld;
+    a.k = k;
+    RAG_HIP_CHECK(hipMemsetAsync(a.gthr, 0, 256, s));
+    const size_t lds = narrow_lds_bytes(h->ld, nj);
+    MergeArgs m = {};
+    m.keys = a.part;
+    m.stride = (long long)a.W_total * k;
+    m.k = k;
+    // the profiling events bracket both scan launches (and the small merge between them): every row is inside
+    if (int rc = profile_begin(h, s)) return rc;
+    if (p.sample) {
+        // 1. the leading rows, 2. their k best per query (scores only matter), which the main launch starts from
+        a.row_begin = 0;
+        a.row_end = p.sample;
+        a.wave_base = 0;
+        if (int rc = launch_narrow_shape(a, nj, p.grid_s, lds, h->device, s)) return rc;
+        m.per_query = p.Ws * k;
+        m.cap = merge_cap(m.per_query, k);
+        m.min_score = -FLT_MAX;
+        m.D = tmpD;
+        m.I = tmpI;
+        RAG_HIP_CHECK(launch_merge_keys(m, nq, s));
+        a.thr_init = tmpD;
+    }
+    a.row_begin = p.sample;
+    a.row_end = h->n;
+    a.wave_base = (int)p.Ws;
+    if (int rc = launch_narrow_shape(a, nj, p.grid_m, lds, h->device, s)) return rc;
+    if (int rc2 = profile_end(h, s)) return rc2;
+    m.per_query = (long long)a.W_total * k;
+    m.cap = merge_cap(m.per_query, k);
+    m.min_score = min_score;
+    m.row_ids = h->ids_dev;
+    m.id_base = h->id_base;
+    m.rows_out = h->merge_rows_out;
+    m.D = D;
+    m.I = I;
+    RAG_HIP_CHECK(launch_merge_keys(m, nq, s));
+    h->last_path = "narrow";
+    return RAG_OK;
+}
+
+}  // namespace rag

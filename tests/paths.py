@@ -1,0 +1,14 @@
+"""Which kernel path the library takes for a flat fp32 search (no bf16 first pass), as
+rag_index_last_path reports it -- mirrors the dispatch of rag_amd/csrc/api.hip so that tests can
+assert that a case exercises the kernel it is meant for."""
+
+
+def flat_fp32_path(n, d, nq, k):
+    ld = (d + 3) // 4 * 4
+    if 5 <= nq <= 32 and k <= 32 and n >= 4096 and ld % 128 == 0:
+        nj = 1 if nq <= 16 else 2
+        if ld * nj * 64 + 8 * 4096 + 8 * nj * 16 * 8 + 48 <= 160 * 1024:
+            return "narrow"
+    if nq >= 5 and k <= 64 and ld % 32 == 0 and n >= 1:
+        return "gemm"
+    return "scan"

@@ -201,7 +201,8 @@ def test_every_small_batch_size(d):
     idx.add(X)
     for nq in (1, 2, 3, 4, 5, 6, 7, 8, 13):
         D, I = idx.search(Q[:nq], k)
-        assert idx.last_path == ("scan" if nq <= 4 or d == 100 else "gemm")
+        from paths import flat_fp32_path
+        assert idx.last_path == flat_fp32_path(n, d, nq, k)
         _check(D, I, X, Q[:nq], k)
     idx.close()
 

@@ -108,8 +108,8 @@ def test_halves_merge_to_whole(corpus):
 
 
 def test_every_gemm_shape_agrees_with_the_scan(corpus):
-    """The four tile shapes (12, 64, 200 and 1100 queries) against single-query scans of the same
-    index: identical ids, scores within tolerance."""
+    """The narrow kernel (12, 32 queries) and the tile shapes of the GEMM kernel (64, 200 and 1100
+    queries) against single-query scans of the same index: identical ids, scores within tolerance."""
     torch, X, Q, idx, planted = corpus
     from bench import make_queries
     Qbig = make_queries(torch, 1100, D, X.device)            # the first 64 equal Q (same seed)
@@ -119,9 +119,9 @@ def test_every_gemm_shape_agrees_with_the_scan(corpus):
         Ds, Is = idx.search(Qbig[qi:qi + 1], K)
         assert idx.last_path == "scan"
         scans[qi] = (Ds.cpu().numpy()[0], Is.cpu().numpy()[0])
-    for nq in (12, 64, 200, 1100):
+    for nq in (12, 32, 64, 200, 1100):
         Dg, Ig = idx.search(Qbig[:nq], K)
-        assert idx.last_path == "gemm"
+        assert idx.last_path == ("narrow" if nq <= 32 else "gemm")
         Dg, Ig = Dg.cpu().numpy(), Ig.cpu().numpy()
         for qi, (Ds, Is) in scans.items():
             if qi < nq:

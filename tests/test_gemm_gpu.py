@@ -43,7 +43,8 @@ def test_gemm_matches_oracle(n, d, nq, k):
     idx = DeviceIndex(d, metric="ip")
     idx.add(X)
     D, I = idx.search(Q, k)
-    assert idx.last_path == "gemm"
+    from paths import flat_fp32_path
+    assert idx.last_path == flat_fp32_path(n, d, nq, k)       # up to 32 queries (k <= 32, 128-float rows): the narrow kernel
     _check(D, I, X, Q, k)
     idx.close()
 
@@ -64,9 +65,11 @@ def test_gemm_adversarial_order_duplicates_and_mask(nq):
     idx = DeviceIndex(d, metric="ip")
     idx.add(X)
     D, I = idx.search(Q, 10)
-    assert idx.last_path == "gemm"
+    from paths import flat_fp32_path
+    assert idx.last_path == flat_fp32_path(n, d, nq, 10)
     _check(D, I, X, Q, 10)
     D, I = idx.search(Q, 64)
+    assert idx.last_path == "gemm"
     _check(D, I, X, Q, 64)
     mask = (rng.uniform(size=n) < 0.2).astype(np.uint8)
     D, I = idx.search(Q, 10, row_mask=mask)
@@ -91,7 +94,7 @@ def test_gemm_and_scan_agree_bitwise_on_ids():
     idx = DeviceIndex(d, metric="ip")
     idx.add(X)
     Dg, Ig = idx.search(Q, 10)
-    assert idx.last_path == "gemm"
+    assert idx.last_path == "narrow"
     rows = [idx.search(Q[i], 10) for i in range(32)]
     assert idx.last_path == "scan"
     Is = np.concatenate([r[1] for r in rows])

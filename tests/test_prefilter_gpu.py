@@ -52,7 +52,8 @@ def test_prefilter_matches_oracle(n, d, nq, k):
     _check(D, I, X, Q, k, row_mask=mask, min_score=0.02)
     idx.set_prefilter(False)
     D2, I2 = idx.search(Q, k, row_mask=mask, min_score=0.02)
-    assert idx.last_path == ("gemm" if nq >= 5 else "scan")
+    from paths import flat_fp32_path
+    assert idx.last_path == flat_fp32_path(n, d, nq, k)
     _check(D2, I2, X, Q, k, row_mask=mask, min_score=0.02)
     idx.close()
 
