@@ -149,12 +149,24 @@ struct GemmArgs {
 #ifndef RAG_GEMM_NARROW_AUX
 #define RAG_GEMM_NARROW_AUX 2
 #endif
-// rare path of the tile epilogue.  Inlined on purpose: as an out-of-line call (accumulators and
-// thresholds live across it, partial exec mask) it was no faster and, once register pressure rose,
-// returned wrong candidates now and then.
+// rare path of the tile epilogue.  Inlined on purpose.  As an out-of-line call (-DRAG_PUSH_OUTLINE,
+// a diagnostic build) the generated code is sound and gives the same results on every GEMM-path
+// test: the callee touches v0..v13 and s0..s9 of the caller-saved set, honours EXEC, and finds
+// s_cnt / s_flag through the dynamic-LDS offset table under the kernel id in s15.  What the call
+// costs is private memory: `const GemmArgs&` then needs an address, so each kernel copies its
+// argument block into scratch at entry and the callee reads mask / row_alias / trig back through
+// flat loads, and the accumulators and thresholds that live across calls made under a partial EXEC
+// mask are spilled around the K loop and inside the divergent epilogue -- 208..352 bytes of scratch
+// per lane and 256 VGPRs in every instantiation, for a path a handful of lanes per tile take.
+// Inlined, the kernels use no scratch, and the build fails if that ever changes.
+#ifdef RAG_PUSH_OUTLINE
+#define RAG_PUSH_ATTR __noinline__
+#else
+#define RAG_PUSH_ATTR __forceinline__
+#endif
 template <int RT, int QT>
-__device__ __forceinline__ void push_candidate(const GemmArgs& a, u64* cand, int* s_cnt, int* s_flag, int ql,
-                                                         long long row, long long row_hi, float sc) {
+__device__ RAG_PUSH_ATTR void push_candidate(const GemmArgs& a, u64* cand, int* s_cnt, int* s_flag, int ql,
+                                             long long row, long long row_hi, float sc) {
     constexpr int CAPQ = gemm_capq(RT, QT);
     if (row < row_hi && (!a.mask || a.mask[row])) {
         const int pos = atomicAdd(&s_cnt[ql], 1);
@@ -233,7 +245,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f16v (&acc)[2][
 #pragma unroll
     for (int nj = 0; nj < NJ; ++nj) {
         const int ql = qbase + nj * 32 + l31;
-        thr[nj] = ql < m_valid ? s_thr[ql] : INFINITY;
+        thr[nj] = s_thr[ql];                                // +inf for the padding queries of the block
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
             float m = -INFINITY;
@@ -339,7 +351,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
     }
 
     for (int i = tid; i < QT; i += NT) {
-        s_thr[i] = -INFINITY;
+        s_thr[i] = i < m_valid ? -INFINITY : INFINITY;      // padding queries keep nothing
         s_cnt[i] = 0;
         if constexpr (B16) s_margin[i] = (q0 + i) < a.nq ? a.margin[q0 + i] : 0.f;
     }
