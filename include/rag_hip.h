@@ -85,6 +85,9 @@ int rag_index_set_id_base(rag_index_t* h, int64_t base);
 int rag_index_set_prefilter(rag_index_t* h, int mode);
 int64_t rag_index_ntotal(const rag_index_t* h);
 int rag_index_dim(const rag_index_t* h);
+/* RAG_METRIC_* / RAG_KIND_* of the index (what a snapshot was written with); -1 for NULL */
+int rag_index_metric(const rag_index_t* h);
+int rag_index_kind(const rag_index_t* h);
 /* vector_db/qdrant_client.py:826-883 soft delete (payload is_active) and
  * restore: rows[i] are row positions; active = 0 hides them from every search. */
 int rag_index_set_active(rag_index_t* h, int64_t n, const int64_t* rows, int active);
@@ -199,6 +202,50 @@ int rag_mmr_select(int64_t n, int d, const void* emb, int emb_is_f64, const doub
 int rag_mmr_select_rows(rag_index_t* h, int64_t n, const int64_t* rows, const double* rel,
                         double lambda, double similarity_threshold, int metric,
                         int max_results, int32_t* out_idx, int32_t* n_out);
+
+/* ---- keyword side: BM25 over a token-id corpus in device memory -----------------------
+ * vector_db/search_manager.py:142-180 (CorpusStatsManager.calculate_bm25_score), :182-263
+ * (normalize_scores, "minmax") and :1159-1213 (_keyword_search: score every candidate,
+ * normalise, drop below min_score, stable sort descending, cut to `limit`).
+ * The reference tokenises the candidate text for every query; here a document's kept tokens
+ * (preprocess_query, :57-66: lower-cased \b\w+\b words, stop words and words of <= 2
+ * characters dropped, or the first three words when nothing is left) are stored ONCE as
+ * vocabulary ids, document after document, and a query brings its term ids (a term outside
+ * the vocabulary: any negative id) with their idf values (:113-121; 0.5 for a term without
+ * one, :170).  fp64, the reference's operation order, no fused multiply-add: bit-identical
+ * scores.  avgdl == 0 (the reference's ZeroDivisionError path with its substring fallback,
+ * :179-180, which needs the text) is refused with RAG_ERR_INVALID. */
+typedef struct rag_bm25 rag_bm25_t;
+int rag_bm25_create(int device, rag_bm25_t** out);
+void rag_bm25_destroy(rag_bm25_t* h);
+int64_t rag_bm25_ndocs(const rag_bm25_t* h);
+/* append n_new documents: doc_len[i] kept tokens each, ids concatenated in `tokens` */
+int rag_bm25_add(rag_bm25_t* h, int64_t n_new, const int64_t* doc_len, const int32_t* tokens);
+int rag_bm25_clear(rag_bm25_t* h);
+/* raw BM25 of m candidate documents (cand[i] = document number; NULL: documents 0..m-1;
+ * a number outside the corpus scores 0.0 like an empty text), 1..64 query terms */
+int rag_bm25_score(rag_bm25_t* h, int64_t m, const int64_t* cand, int n_terms, const int32_t* term_ids,
+                   const double* term_idf, double avgdl, double k1, double b, double* raw_out);
+int rag_bm25_score_device(rag_bm25_t* h, int64_t m, const int64_t* cand_dev, int n_terms,
+                          const int32_t* term_ids_dev, const double* term_idf_dev, double avgdl,
+                          double k1, double b, double* raw_out_dev, void* stream);
+/* score, normalise (min-max over the m candidates; all equal -> 0.0 if zero else 1.0; a single
+ * candidate -> sigmoid 1/(1+exp(-2s))), keep normalised >= min_score when use_min_score, stable
+ * sort descending, first `limit` (1..4096; m <= 4096).  out_rows / out_norm / out_raw [limit]:
+ * document numbers, normalised and raw scores, padded with -1 / 0.0 beyond *n_out -- the layout
+ * rag_index_hybrid_mmr[_device] takes as its keyword hits. */
+int rag_bm25_rank(rag_bm25_t* h, int64_t m, const int64_t* cand, int n_terms, const int32_t* term_ids,
+                  const double* term_idf, double avgdl, double k1, double b, int use_min_score,
+                  double min_score, int limit, int64_t* out_rows, double* out_norm, double* out_raw,
+                  int32_t* n_out);
+/* device pointers, enqueued on `stream`, not synchronised; raw_scratch_dev [m] doubles.  The
+ * single-candidate sigmoid uses the device exp (within 1 ulp of libm; the host form above
+ * recomputes it with libm). */
+int rag_bm25_rank_device(rag_bm25_t* h, int64_t m, const int64_t* cand_dev, int n_terms,
+                         const int32_t* term_ids_dev, const double* term_idf_dev, double avgdl,
+                         double k1, double b, int use_min_score, double min_score, int limit,
+                         double* raw_scratch_dev, int64_t* out_rows_dev, double* out_norm_dev,
+                         double* out_raw_dev, int32_t* n_out_dev, void* stream);
 
 /* ---- search -> hybrid fusion -> MMR as one enqueue ---------------------------------
  * vector_db/search_manager.py:938-970 (_contextual_search: semantic hits + keyword hits ->

@@ -44,6 +44,8 @@ SIGNATURES = {
     "rag_index_set_prefilter": (_i32, [_vp, _i32]),
     "rag_index_ntotal": (_i64, [_vp]),
     "rag_index_dim": (_i32, [_vp]),
+    "rag_index_metric": (_i32, [_vp]),
+    "rag_index_kind": (_i32, [_vp]),
     "rag_index_set_active": (_i32, [_vp, _i64, _vp, _i32]),
     "rag_index_reconstruct": (_i32, [_vp, _i64, _vp, _vp]),
     "rag_index_save": (_i32, [_vp, C.c_char_p]),
@@ -65,6 +67,16 @@ SIGNATURES = {
                                     _i32, _vp]),
     "rag_index_hybrid_mmr_device": (_i32, [_vp, _vp, _i32, _f32, _i32, _vp, _i64, _vp, _vp, _f64, _f64, _i32, _f64, _f64,
                                            _i32, _i32, _vp, _vp]),
+    "rag_bm25_create": (_i32, [_i32, C.POINTER(_vp)]),
+    "rag_bm25_destroy": (None, [_vp]),
+    "rag_bm25_ndocs": (_i64, [_vp]),
+    "rag_bm25_add": (_i32, [_vp, _i64, _vp, _vp]),
+    "rag_bm25_clear": (_i32, [_vp]),
+    "rag_bm25_score": (_i32, [_vp, _i64, _vp, _i32, _vp, _vp, _f64, _f64, _f64, _vp]),
+    "rag_bm25_score_device": (_i32, [_vp, _i64, _vp, _i32, _vp, _vp, _f64, _f64, _f64, _vp, _vp]),
+    "rag_bm25_rank": (_i32, [_vp, _i64, _vp, _i32, _vp, _vp, _f64, _f64, _f64, _i32, _f64, _i32, _vp, _vp, _vp, _vp]),
+    "rag_bm25_rank_device": (_i32, [_vp, _i64, _vp, _i32, _vp, _vp, _f64, _f64, _f64, _i32, _f64, _i32, _vp, _vp, _vp, _vp,
+                                    _vp, _vp]),
 }
 
 

@@ -151,3 +151,153 @@ class CorpusStatsManager:
         rows = [(i, n, r) for i, (n, r) in enumerate(zip(norm, raw)) if min_score is None or n >= min_score]
         rows.sort(key=lambda t: t[1], reverse=True)
         return rows[:limit]
+
+
+class DeviceKeywordIndex:
+    """The keyword corpus on the GPU.  A text is tokenised once, when it is added
+    (``preprocess_query``, vector_db/search_manager.py:57-66); its kept tokens go to HBM as
+    vocabulary ids.  A query then costs one small launch: term frequencies, BM25
+    (:142-180), min-max normalisation (:182-263), the ``min_score`` filter and the stable
+    descending sort of ``_keyword_search`` (:1159-1213) run on the device with the
+    reference's fp64 operation order, so scores are bit-identical to ``CorpusStatsManager``.
+    Document numbers are positions in the order of ``add_texts``: use the same order as the
+    rows of the vector index and the ranked hits feed ``hybrid_mmr`` as they are."""
+
+    MAX_TERMS = 64
+    MAX_RANK = 4096
+
+    def __init__(self, device: int = 0, stats_manager: Optional[CorpusStatsManager] = None):
+        import ctypes as C
+        from . import _lib
+        self._C, self._lib = C, _lib
+        self.manager = stats_manager or CorpusStatsManager()
+        self.device = device
+        self.vocab: Dict[str, int] = {}
+        self._doc_ids: List[Any] = []          # per document: numpy int32 token ids (host copy for the statistics)
+        h = C.c_void_p()
+        _lib.check(_lib.lib.rag_bm25_create(device, C.byref(h)))
+        self._h = h
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.lib.rag_bm25_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self) -> int:
+        return len(self._doc_ids)
+
+    def add_texts(self, texts: Sequence[Optional[str]]) -> range:
+        import numpy as np
+        first = len(self._doc_ids)
+        docs = []
+        for text in texts:
+            ids = [self.vocab.setdefault(t, len(self.vocab)) for t in self.manager.preprocess_query(text or "")]
+            docs.append(np.asarray(ids, dtype=np.int32))
+        if docs:
+            lens = np.asarray([d.size for d in docs], dtype=np.int64)
+            flat = np.ascontiguousarray(np.concatenate(docs) if lens.sum() else np.zeros(0, np.int32), dtype=np.int32)
+            self._lib.check(self._lib.lib.rag_bm25_add(self._h, len(docs), lens.ctypes.data, flat.ctypes.data if flat.size else None))
+            self._doc_ids.extend(docs)
+        return range(first, len(self._doc_ids))
+
+    def corpus_stats(self, docs: Optional[Sequence[int]] = None) -> Dict[str, Any]:
+        """``compute_corpus_stats`` (:87-127) over the stored documents (or the given subset)."""
+        import numpy as np
+        chosen = self._doc_ids if docs is None else [self._doc_ids[i] for i in docs]
+        if not chosen:
+            return self.manager._get_default_stats()
+        n = len(chosen)
+        lengths = [int(d.size) for d in chosen]
+        uniq = [np.unique(d) for d in chosen]
+        df = np.bincount(np.concatenate(uniq), minlength=len(self.vocab)) if sum(u.size for u in uniq) else np.zeros(0, np.int64)
+        terms = list(self.vocab)
+        return {"total_docs": n, "avg_doc_length": sum(lengths) / len(lengths),
+                "idf": {terms[t]: max(math.log((n - int(f) + 0.5) / (int(f) + 0.5)), 0.01) for t, f in enumerate(df) if f}}
+
+    def _terms(self, query_terms: Sequence[str], stats: Dict[str, Any]):
+        import numpy as np
+        if len(query_terms) > self.MAX_TERMS:
+            raise ValueError(f"at most {self.MAX_TERMS} query terms")
+        idf = stats.get("idf", {})
+        ids = np.asarray([self.vocab.get(t, -1) for t in query_terms], dtype=np.int32)
+        w = np.asarray([idf.get(t, 0.5) for t in query_terms], dtype=np.float64)
+        avgdl = float(stats.get("avg_doc_length", 100))
+        if avgdl == 0.0:
+            raise ValueError("avg_doc_length == 0: the reference's substring fallback needs the texts (CorpusStatsManager)")
+        return ids, w, avgdl
+
+    def score(self, query_terms: Sequence[str], candidates: Optional[Sequence[int]] = None,
+              stats: Optional[Dict[str, Any]] = None, k1: float = 1.5, b: float = 0.75) -> List[float]:
+        """``calculate_bm25_score`` for every candidate document (default: all), one launch."""
+        import numpy as np
+        m = len(self) if candidates is None else len(candidates)
+        if not query_terms or m == 0:
+            return [0.0] * m
+        stats = stats if stats is not None else self.corpus_stats()
+        ids, w, avgdl = self._terms(query_terms, stats)
+        cand = None if candidates is None else np.ascontiguousarray(candidates, dtype=np.int64)
+        out = np.empty(m, dtype=np.float64)
+        self._lib.check(self._lib.lib.rag_bm25_score(self._h, m, None if cand is None else cand.ctypes.data, len(ids),
+                                                     ids.ctypes.data, w.ctypes.data, avgdl, k1, b, out.ctypes.data))
+        return out.tolist()
+
+    def rank(self, query: str, candidates: Optional[Sequence[int]] = None, limit: int = 10,
+             min_score: Optional[float] = None, stats: Optional[Dict[str, Any]] = None,
+             k1: float = 1.5, b: float = 0.75):
+        """``_keyword_search`` after its SQL prefilter: [(document, normalised, raw)] best first."""
+        import numpy as np
+        terms = self.manager.preprocess_query(query)
+        m = len(self) if candidates is None else len(candidates)
+        if not terms or m == 0:
+            return []
+        stats = stats if stats is not None else self.corpus_stats()
+        ids, w, avgdl = self._terms(terms, stats)
+        cand = None if candidates is None else np.ascontiguousarray(candidates, dtype=np.int64)
+        rows = np.empty(limit, dtype=np.int64)
+        norm = np.empty(limit, dtype=np.float64)
+        raw = np.empty(limit, dtype=np.float64)
+        n = self._C.c_int(0)
+        self._lib.check(self._lib.lib.rag_bm25_rank(
+            self._h, m, None if cand is None else cand.ctypes.data, len(ids), ids.ctypes.data, w.ctypes.data, avgdl, k1, b,
+            0 if min_score is None else 1, 0.0 if min_score is None else float(min_score), limit,
+            rows.ctypes.data, norm.ctypes.data, raw.ctypes.data, self._C.byref(n)))
+        return [(int(rows[i]), float(norm[i]), float(raw[i])) for i in range(n.value)]
+
+    def rank_device(self, query: str, candidates=None, limit: int = 10, min_score: Optional[float] = None,
+                    stats: Optional[Dict[str, Any]] = None, k1: float = 1.5, b: float = 0.75):
+        """The same ranking with torch CUDA tensors in and out and no synchronisation:
+        (rows int64[limit] padded with -1, normalised float64[limit], raw float64[limit], count int32[1]) --
+        ``rows`` / ``normalised`` are what ``hybrid_mmr`` takes as ``bm25_rows`` / ``bm25_scores``.
+        ``candidates``: int64 CUDA tensor of document numbers, or None for every document (at most 4096)."""
+        import torch
+        dev = torch.device("cuda", self.device)
+        terms = self.manager.preprocess_query(query)
+        m = len(self) if candidates is None else int(candidates.numel())
+        rows = torch.full((limit,), -1, dtype=torch.int64, device=dev)
+        norm = torch.zeros(limit, dtype=torch.float64, device=dev)
+        raw = torch.zeros(limit, dtype=torch.float64, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        if not terms or m == 0:
+            return rows, norm, raw, cnt
+        stats = stats if stats is not None else self.corpus_stats()
+        ids, w, avgdl = self._terms(terms, stats)
+        ids_d = torch.from_numpy(ids).to(dev, non_blocking=True)
+        w_d = torch.from_numpy(w).to(dev, non_blocking=True)
+        if candidates is not None and (candidates.dtype != torch.int64 or not candidates.is_cuda or not candidates.is_contiguous()):
+            raise ValueError("candidates must be a contiguous int64 CUDA tensor")
+        scratch = torch.empty(m, dtype=torch.float64, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        self._lib.check(self._lib.lib.rag_bm25_rank_device(
+            self._h, m, None if candidates is None else candidates.data_ptr(), len(ids), ids_d.data_ptr(), w_d.data_ptr(),
+            avgdl, k1, b, 0 if min_score is None else 1, 0.0 if min_score is None else float(min_score), limit,
+            scratch.data_ptr(), rows.data_ptr(), norm.data_ptr(), raw.data_ptr(), cnt.data_ptr(), stream))
+        # the staging tensors must outlive the enqueued work: tie them to the stream
+        for t in (ids_d, w_d, scratch):
+            t.record_stream(torch.cuda.current_stream(dev))
+        return rows, norm, raw, cnt

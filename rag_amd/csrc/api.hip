@@ -488,6 +488,8 @@ int rag_index_set_id_base(rag_index_t* h, int64_t base) {
 
 int64_t rag_index_ntotal(const rag_index_t* h) { return h ? h->n : 0; }
 int rag_index_dim(const rag_index_t* h) { return h ? h->dim : 0; }
+int rag_index_metric(const rag_index_t* h) { return h ? h->metric : -1; }
+int rag_index_kind(const rag_index_t* h) { return h ? h->kind : -1; }
 const char* rag_index_last_path(const rag_index_t* h) { return h ? h->last_path : "none"; }
 
 int rag_index_set_active(rag_index_t* h, int64_t n, const int64_t* rows, int active) {

@@ -730,8 +730,12 @@ __global__ void rows_to_bf16_kernel(const float* X, long long r0, long long r1, 
 }
 
 // padded fp32 queries -> bf16 copies and the per-query margin 2 * delta,
-// delta = PREF_ERR * (largest row norm) * (query norm)
-constexpr float PREF_ERR = 0.0042f;      // 2 * 2^-9 (both operands rounded) + 2^-18 + accumulation slack
+// delta = pref_err(ld) * (largest row norm) * (query norm)
+// |approximate - exact| <= pref_err(ld) * |x| * |q|: both operands rounded to bf16 (relative 2^-9 each:
+// 2^-8 + 2^-18 on the product, which is exact in fp32) plus the worst case of ld fp32 additions
+// (ld * 2^-24, with 1 % on top for the rounded operands).  768 floats: 0.00396; the bound grows with the
+// row width instead of running out of slack at a few thousand floats.
+__host__ __device__ inline float pref_err(int ld) { return 0.00390625f + 3.8147e-6f + 1.01f * (float)ld * 5.9604645e-8f; }
 __global__ void queries_to_bf16_kernel(const float* Q, int ld, const int* maxnorm_bits, __bf16* Qb, float* margin) {
     const long long q = blockIdx.x;
     const int lane = threadIdx.x;            // one wave per query
@@ -743,7 +747,7 @@ __global__ void queries_to_bf16_kernel(const float* Q, int ld, const int* maxnor
         Qb[q * ld + i] = (__bf16)v;
     }
     ss = wave_sum_to_lane63(ss);
-    if (lane == 63) margin[q] = 2.f * PREF_ERR * __int_as_float(*maxnorm_bits) * sqrtf(ss) * 1.0001f + 1e-30f;
+    if (lane == 63) margin[q] = 2.f * pref_err(ld) * __int_as_float(*maxnorm_bits) * sqrtf(ss) * 1.0001f + 1e-30f;
 }
 
 
@@ -1147,12 +1151,13 @@ int ivf_listmajor_scan(rag_index* h, long long nq, const float* qbuf, int k, flo
 // fp32 and accepts the k best exact ones only if the k-th of them beats (worst kept approximate
 // score + delta), delta >= |approximate - exact| for every row: then no row outside the kept set
 // can reach the top k.  Otherwise it raises the flag and the fp32 scan enqueued behind it
-// (run_if = flag) answers.  The query stays fp32, so delta = PREF_ERR1 * max row norm * |q|.
+// (run_if = flag) answers.  The query stays fp32, so delta = pref_err1(ld) * max row norm * |q|.
 constexpr int PRE1_MAX = 1024;
 // rows kept by the approximate scan for a request of k: 64 (register lists) up to k = 16, 1024
 // (LDS lists) up to k = 256
 static int pre1_for(int k) { return k <= 16 ? 64 : 1024; }
-constexpr float PREF_ERR1 = 0.0021f;     // 2^-9 (rows rounded to bf16) + accumulation slack
+// rows rounded to bf16 (2^-9), the query exact, ld fp32 additions in the worst case
+__host__ __device__ inline float pref_err1(int ld) { return 0.001953125f + 1.01f * (float)ld * 5.9604645e-8f; }
 
 int scan_blocks(const rag_index* h, int k);     // api.hip
 
@@ -1210,7 +1215,7 @@ __global__ __launch_bounds__(1024) void verify_rescore_kernel(VerifyArgs v) {
     bitonic_sort_desc_lds(keys, PRE1, tid, blockDim.x, SyncBlock());
     // the kept set is everything when the list is not full; else rows outside score at most Dk[PRE1-1] + delta
     const bool full = v.Ik[PRE1 - 1] >= 0;
-    const float delta = PREF_ERR1 * __int_as_float(*v.maxnorm_bits) * s_qn * 1.0001f + 1e-30f;
+    const float delta = pref_err1(v.ld) * __int_as_float(*v.maxnorm_bits) * s_qn * 1.0001f + 1e-30f;
     const bool enough = keys[k - 1] != KEY_EMPTY;
     const bool ok = !full || (enough && key_score(keys[k - 1]) > v.Dk[PRE1 - 1] + delta);
     if (tid == 0) *v.flag = ok ? 0 : 1;

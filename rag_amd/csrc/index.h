@@ -50,6 +50,7 @@ struct IvfState {
     int nlist = 0;
     rag_index* quantizer = nullptr;       // FLAT inner-product index over the centroids
     std::vector<int> assign;              // insertion position -> list
+    const int* preassigned = nullptr;     // while set (snapshot load): lists of the rows being added, by insertion position
     std::vector<long long> orig;          // storage position -> insertion position
     std::vector<long long> pos;           // insertion position -> storage position
     long long n_packed = 0;               // rows [0, n_packed) of X are in list order

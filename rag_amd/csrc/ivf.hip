@@ -91,6 +91,15 @@ int ivf_assign_new_rows(rag_index* h, long long first, long long count) {
     IvfState& v = h->ivf;
     if (!v.quantizer) return fail(RAG_ERR_INVALID, "IVF index is not trained");
     v.assign.resize((size_t)(first + count));
+    if (v.preassigned) {
+        // rows of a snapshot come back with the lists they had
+        for (long long i = 0; i < count; ++i) {
+            const int l = v.preassigned[(size_t)(first + i)];
+            if (l < 0 || l >= v.nlist) return fail(RAG_ERR_INVALID, "snapshot names a list outside [0, nlist)");
+            v.assign[(size_t)(first + i)] = l;
+        }
+        return RAG_OK;
+    }
     const long long chunk = 65536;
     std::vector<long long> host_i((size_t)std::min(chunk, count));
     for (long long c0 = 0; c0 < count; c0 += chunk) {

@@ -1,12 +1,17 @@
-// Binary snapshot of a FLAT index: what the reference's JSON backup of a Qdrant
+// Binary snapshot of an index: what the reference's JSON backup of a Qdrant
 // collection (vector_db/qdrant_client.py:475-621, every vector as a list of
 // Python floats) becomes when the vectors live in HBM.
 //
-//   header   magic "RAGHIP01", dim, metric, n, id_base, flags (bit0 ids, bit1 active)
-//   rows     n x dim fp32, row-major, as stored (COSINE rows are normalised)
-//   ids      n x int64            (flag bit 0)
-//   active   n x uint8            (flag bit 1)
-// Payloads stay with the caller (a JSON sidecar written by the Python layer).
+//   header     magic "RAGHIP01", dim, metric, n, id_base, flags (bit0 ids, bit1 active,
+//              bit2 IVF), nlist (IVF, else 0)
+//   centroids  nlist x dim fp32      (IVF)
+//   lists      n x int32             (IVF: the list of every row, insertion order)
+//   rows       n x dim fp32, row-major, insertion order, as stored (COSINE rows are normalised)
+//   ids        n x int64             (flag bit 0)
+//   active     n x uint8             (flag bit 1)
+// An IVF index comes back with the lists its rows had: nothing is re-assigned on load, so a
+// row at a coarse tie stays where it was.  Payloads stay with the caller (a JSON sidecar
+// written by the Python layer).
 #include <stdio.h>
 #include <string.h>
 
@@ -25,7 +30,7 @@ struct SnapHeader {
     int64_t n;
     int64_t id_base;
     int32_t flags;
-    int32_t reserved;
+    int32_t nlist;
 };
 const char kMagic[8] = {'R', 'A', 'G', 'H', 'I', 'P', '0', '1'};
 struct FileCloser {
@@ -37,7 +42,8 @@ struct FileCloser {
 extern "C" int rag_index_save(rag_index_t* h, const char* path) {
     if (!h || !path) return fail(RAG_ERR_INVALID, "NULL argument");
     RAG_LOCK_INDEX(h);
-    if (h->kind != RAG_KIND_FLAT) return fail(RAG_ERR_UNSUPPORTED, "snapshots cover FLAT indexes");
+    const bool ivf = h->kind == RAG_KIND_IVF;
+    if (ivf && !h->ivf.quantizer) return fail(RAG_ERR_INVALID, "IVF index is not trained");
     FILE* f = fopen(path, "wb");
     if (!f) return fail(RAG_ERR_INVALID, std::string("cannot open for writing: ") + path);
     FileCloser fc{f};
@@ -52,19 +58,45 @@ extern "C" int rag_index_save(rag_index_t* h, const char* path) {
     hd.metric = h->metric;
     hd.n = h->n;
     hd.id_base = h->id_base;
-    hd.flags = (h->ids_dev ? 1 : 0) | (h->active ? 2 : 0);
+    hd.flags = (h->ids_dev ? 1 : 0) | (h->active ? 2 : 0) | (ivf ? 4 : 0);
+    hd.nlist = ivf ? h->ivf.nlist : 0;
     if (fwrite(&hd, sizeof(hd), 1, f) != 1) return fail(RAG_ERR_INVALID, "write failed");
-    // rows, 64 MiB at a time, padding stripped
     const long long chunk = std::max<long long>(1, (64LL << 20) / ((long long)h->ld * 4));
-    std::vector<float> host((size_t)std::min<long long>(chunk, std::max<long long>(h->n, 1)) * h->ld);
-    for (long long r0 = 0; r0 < h->n; r0 += chunk) {
-        const long long c = std::min(chunk, h->n - r0);
-        RAG_HIP_CHECK(hipMemcpy(host.data(), h->X + (size_t)r0 * h->ld, (size_t)c * h->ld * sizeof(float), hipMemcpyDeviceToHost));
-        if (h->ld == h->dim) {
+    if (ivf) {
+        // centroids (rows of the quantizer, a FLAT index) and every row's list
+        rag_index* qz = h->ivf.quantizer;
+        std::vector<float> cen((size_t)std::min<long long>(chunk, hd.nlist) * h->dim);
+        std::vector<int64_t> which;
+        for (long long r0 = 0; r0 < hd.nlist; r0 += chunk) {
+            const long long c = std::min<long long>(chunk, hd.nlist - r0);
+            which.resize((size_t)c);
+            for (long long i = 0; i < c; ++i) which[(size_t)i] = r0 + i;
+            if (int rc = rag_index_reconstruct(qz, c, which.data(), cen.data())) return rc;
+            if (fwrite(cen.data(), sizeof(float), (size_t)c * h->dim, f) != (size_t)c * h->dim) return fail(RAG_ERR_INVALID, "write failed");
+        }
+        if ((long long)h->ivf.assign.size() < h->n) return fail(RAG_ERR_HIP, "IVF bookkeeping is shorter than the index");
+        if (h->n > 0 && fwrite(h->ivf.assign.data(), sizeof(int), (size_t)h->n, f) != (size_t)h->n) return fail(RAG_ERR_INVALID, "write failed");
+        // rows in insertion order (storage is grouped by list)
+        std::vector<float> host((size_t)std::min<long long>(chunk, std::max<long long>(h->n, 1)) * h->dim);
+        for (long long r0 = 0; r0 < h->n; r0 += chunk) {
+            const long long c = std::min(chunk, h->n - r0);
+            which.resize((size_t)c);
+            for (long long i = 0; i < c; ++i) which[(size_t)i] = r0 + i;
+            if (int rc = rag_index_reconstruct(h, c, which.data(), host.data())) return rc;
             if (fwrite(host.data(), sizeof(float), (size_t)c * h->dim, f) != (size_t)c * h->dim) return fail(RAG_ERR_INVALID, "write failed");
-        } else {
-            for (long long r = 0; r < c; ++r)
-                if (fwrite(host.data() + (size_t)r * h->ld, sizeof(float), (size_t)h->dim, f) != (size_t)h->dim) return fail(RAG_ERR_INVALID, "write failed");
+        }
+    } else {
+        // rows, 64 MiB at a time, padding stripped
+        std::vector<float> host((size_t)std::min<long long>(chunk, std::max<long long>(h->n, 1)) * h->ld);
+        for (long long r0 = 0; r0 < h->n; r0 += chunk) {
+            const long long c = std::min(chunk, h->n - r0);
+            RAG_HIP_CHECK(hipMemcpy(host.data(), h->X + (size_t)r0 * h->ld, (size_t)c * h->ld * sizeof(float), hipMemcpyDeviceToHost));
+            if (h->ld == h->dim) {
+                if (fwrite(host.data(), sizeof(float), (size_t)c * h->dim, f) != (size_t)c * h->dim) return fail(RAG_ERR_INVALID, "write failed");
+            } else {
+                for (long long r = 0; r < c; ++r)
+                    if (fwrite(host.data() + (size_t)r * h->ld, sizeof(float), (size_t)h->dim, f) != (size_t)h->dim) return fail(RAG_ERR_INVALID, "write failed");
+            }
         }
     }
     if (h->ids_dev && h->n > 0) {
@@ -88,20 +120,34 @@ extern "C" int rag_index_load(const char* path, int device, rag_index_t** out) {
     FileCloser fc{f};
     SnapHeader hd;
     if (fread(&hd, sizeof(hd), 1, f) != 1 || memcmp(hd.magic, kMagic, 8) != 0) return fail(RAG_ERR_INVALID, "not a rag_hip snapshot");
-    if (hd.n < 0 || hd.dim < 1) return fail(RAG_ERR_INVALID, "corrupt snapshot header");
+    const bool ivf = (hd.flags & 4) != 0;
+    if (hd.n < 0 || hd.dim < 1 || (hd.flags & ~7) != 0 || (ivf ? hd.nlist < 1 : hd.nlist != 0))
+        return fail(RAG_ERR_INVALID, "corrupt snapshot header");
+    if (hd.metric != RAG_METRIC_IP && hd.metric != RAG_METRIC_COSINE) return fail(RAG_ERR_INVALID, "snapshot names an unknown metric");
     rag_index* h = nullptr;
     // rows in the file are already normalised for COSINE: load them as they are, then restore the metric
-    if (int rc = rag_index_create(hd.dim, RAG_METRIC_IP, RAG_KIND_FLAT, device, &h)) return rc;
+    if (int rc = rag_index_create(hd.dim, RAG_METRIC_IP, ivf ? RAG_KIND_IVF : RAG_KIND_FLAT, device, &h)) return rc;
     struct Guard { rag_index* h; bool keep; ~Guard() { if (!keep) rag_index_free(h); } } guard{h, false};
     if (int rc = rag_index_set_id_base(h, hd.id_base)) return rc;
-    if (int rc = rag_index_reserve(h, hd.n)) return rc;
     const long long chunk = std::max<long long>(1, (64LL << 20) / ((long long)hd.dim * 4));
+    std::vector<int> lists;
+    if (ivf) {
+        std::vector<float> cen((size_t)hd.nlist * hd.dim);
+        if (fread(cen.data(), sizeof(float), cen.size(), f) != cen.size()) return fail(RAG_ERR_INVALID, "truncated snapshot (centroids)");
+        if (int rc = rag_index_train_ivf(h, hd.nlist, cen.data(), 0, nullptr)) return rc;
+        lists.resize((size_t)hd.n);
+        if (hd.n > 0 && fread(lists.data(), sizeof(int), (size_t)hd.n, f) != (size_t)hd.n) return fail(RAG_ERR_INVALID, "truncated snapshot (lists)");
+        h->ivf.preassigned = lists.data();
+    }
+    struct Unset { rag_index* h; ~Unset() { h->ivf.preassigned = nullptr; } } unset{h};
+    if (int rc = rag_index_reserve(h, hd.n)) return rc;
     std::vector<float> host((size_t)std::min<long long>(chunk, std::max<long long>(hd.n, 1)) * hd.dim);
     for (long long r0 = 0; r0 < hd.n; r0 += chunk) {
         const long long c = std::min(chunk, hd.n - r0);
         if (fread(host.data(), sizeof(float), (size_t)c * hd.dim, f) != (size_t)c * hd.dim) return fail(RAG_ERR_INVALID, "truncated snapshot (rows)");
         if (int rc = rag_index_add(h, c, host.data(), nullptr)) return rc;
     }
+    h->ivf.preassigned = nullptr;
     h->metric = hd.metric;
     int prev = 0;
     RAG_HIP_CHECK(hipGetDevice(&prev));

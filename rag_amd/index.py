@@ -84,8 +84,8 @@ class DeviceIndex:
         self._keepalive = None
         self.dim = int(lib.rag_index_dim(h))
         self.device = int(device)
-        self.kind = "flat"
-        self.metric = "snapshot"
+        self.kind = "ivf" if int(lib.rag_index_kind(h)) == _lib.KIND_IVF else "flat"
+        self.metric = "cosine" if int(lib.rag_index_metric(h)) == _lib.METRIC_COSINE else "ip"
         return self
 
     # --------------------------------------------------------------- measurement

@@ -24,7 +24,7 @@ import numpy as np
 
 from .filters import payload_passes
 from .index import DeviceIndex
-from .schemas import Chunk, SearchConfig, SearchError
+from .schemas import Chunk, SearchConfig, SearchError, device_limit
 
 
 class PooledCollections:
@@ -62,16 +62,18 @@ class PooledCollections:
             self.ranges.setdefault(name, [])
             return
         first = len(self.payloads)
-        stale = [rows[i] for i in ids if i in rows]
         self.index.add(x)
         rng = self.ranges.setdefault(name, [])
         if rng and rng[-1][1] == first:
             rng[-1][1] = first + x.shape[0]                 # contiguous with the previous add
         else:
             rng.append([first, first + x.shape[0]])
+        stale = []
         for j, (p, i) in enumerate(zip(payloads, ids)):
             self.payloads.append(dict(p) if p else {})
             self.point_ids.append(i)
+            if i in rows:                                   # an earlier point with this id, of this batch too: the last one wins
+                stale.append(rows[i])
             rows[i] = first + j
         if stale:
             self.index.set_active(stale, False)
@@ -138,6 +140,39 @@ class PooledCollections:
         self._version += 1
         self._mask_cache.clear()
         return dead
+
+    def backup(self, path: str) -> Dict[str, Any]:
+        """vector_db/qdrant_client.py:475-621 backup_collection for the whole pool: the device corpus
+        as one binary snapshot (`path`), collections / payloads / point ids as a JSON sidecar."""
+        import json
+        self.index.save(path)
+        with open(path + ".json", "w") as f:
+            json.dump({"dimension": self.dimension, "metric": self.index.metric, "ranges": self.ranges,
+                       "payloads": self.payloads, "point_ids": self.point_ids,
+                       "rows": [[name, [[pid, r] for pid, r in rows.items()]] for name, rows in self._rows.items()],
+                       "hidden": sorted(self._hidden)}, f)
+        return {"collections": len(self.ranges), "points_count": sum(len(r) for r in self._rows.values()), "path": path}
+
+    @classmethod
+    def restore(cls, path: str, device: int = 0) -> "PooledCollections":
+        """vector_db/qdrant_client.py:623-764 restore_collection for a pool written by ``backup``."""
+        import json
+        with open(path + ".json") as f:
+            meta = json.load(f)
+        self = cls.__new__(cls)
+        self.dimension = meta["dimension"]
+        self.index = DeviceIndex.load(path, device=device)
+        if self.index.dim != self.dimension:
+            self.index.close()
+            raise SearchError("snapshot dimension differs from its sidecar")
+        self.ranges = {name: [list(r) for r in rs] for name, rs in meta["ranges"].items()}
+        self.payloads = meta["payloads"]
+        self.point_ids = meta["point_ids"]
+        self._rows = {name: {(tuple(pid) if isinstance(pid, list) else pid): r for pid, r in rows} for name, rows in meta["rows"]}
+        self._hidden = set(meta["hidden"])
+        self._version = 0
+        self._mask_cache = {}
+        return self
 
     def get_vector(self, name: str, point_id) -> Optional[np.ndarray]:
         row = self.row_of(name, point_id)
@@ -288,7 +323,7 @@ class PooledView:
             if limit < 1:
                 return [[] for _ in range(q.shape[0])]
             names = [self.collection_name]
-            hits = self.pool.search_many(names, q, min(int(limit), 1024), min_score=min_score,
+            hits = self.pool.search_many(names, q, device_limit(limit), min_score=min_score,
                                          row_mask=self.pool.filter_mask(names, filters))
             return [self.pool.chunks_of(hits[i][0]) for i in range(q.shape[0])]
         except Exception as e:

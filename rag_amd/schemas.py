@@ -120,3 +120,15 @@ class SearchFilters:
             raise ValueError("mmr_max_results must be in [1, 100]")
         if self.mmr_similarity_metric not in ("cosine", "euclidean", "dot_product"):
             raise ValueError("mmr_similarity_metric must be cosine, euclidean or dot_product")
+
+
+MAX_DEVICE_LIMIT = 1024
+
+
+def device_limit(limit: int) -> int:
+    """The device keeps at most 1024 hits per query (one workgroup merges them); a larger
+    ``limit`` is an error, not a silently shorter answer."""
+    limit = int(limit)
+    if limit > MAX_DEVICE_LIMIT:
+        raise ValueError(f"limit {limit} exceeds the device top-k bound of {MAX_DEVICE_LIMIT}")
+    return limit

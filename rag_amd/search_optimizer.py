@@ -22,7 +22,7 @@ import numpy as np
 
 from .filters import payload_passes
 from .index import DeviceIndex
-from .schemas import Chunk, IndexType, MetricType, SearchConfig, SearchError
+from .schemas import Chunk, IndexType, MetricType, SearchConfig, SearchError, device_limit
 
 _METRIC = {MetricType.COSINE: "cosine", MetricType.DOT_PRODUCT: "ip"}
 
@@ -62,11 +62,13 @@ class HipSearchOptimizer:
         if x.shape[0] == 0:
             return []
         first = len(self.payloads)
-        stale = [self._row_of[i] for i in ids if i in self._row_of]
         self.index.add(x)
+        stale = []
         for j, (p, i) in enumerate(zip(payloads, ids)):
             self.payloads.append(dict(p) if p else {})
             self.point_ids.append(i)
+            if i in self._row_of:                 # an earlier point with this id, of this batch too: the last one wins
+                stale.append(self._row_of[i])
             self._row_of[i] = first + j
         self._version += 1
         if stale:
@@ -139,7 +141,7 @@ class HipSearchOptimizer:
             if limit < 1:
                 return [[] for _ in range(q.shape[0])]
             nprobe = (search_params or {}).get("nprobe", self.config.nprobe)
-            D, I = self.index.search(q, min(int(limit), 1024), min_score=min_score, nprobe=nprobe,
+            D, I = self.index.search(q, device_limit(limit), min_score=min_score, nprobe=nprobe,
                                      row_mask=self._mask(filters))
             return [self._to_chunks(D[i], I[i]) for i in range(q.shape[0])]
         except Exception as e:

@@ -17,7 +17,7 @@ from datetime import datetime, timezone
 from typing import Any, Dict, List, Optional, Tuple
 
 from . import fusion
-from .schemas import MetricType, SearchConfig
+from .schemas import MetricType, SearchConfig, device_limit
 from .pooled import PooledCollections, PooledView
 from .search_optimizer import HipSearchOptimizer
 
@@ -177,7 +177,7 @@ class VectorStorageManager:
                     continue
                 names = [view.collection_name for _ni, view in members]
                 try:
-                    hits = pool.search_many(names, query_vectors, min(int(limit), 1024), min_score=min_score,
+                    hits = pool.search_many(names, query_vectors, device_limit(limit), min_score=min_score,
                                             row_mask=pool.filter_mask(names, metadata_filters))
                     for qi in range(len(hits)):
                         for (ni, _view), h in zip(members, hits[qi]):

@@ -205,3 +205,27 @@ def test_backup_restore_roundtrip(tmp_path):
         assert run(opt2.get_vector_count()) == n
         assert opt2.get_vector("c0")["payload"]["text"] == "v2"
         run(opt2.delete_collection())
+
+
+def test_duplicate_ids_in_one_batch_and_oversized_limit():
+    """The last point of a batch that names an id twice wins (Qdrant upsert semantics,
+    vector_db/qdrant_client.py:207-246); a limit beyond the device bound is an error, not a shorter answer."""
+    from rag_amd.schemas import MetricType, SearchConfig, SearchError
+    from rag_amd.search_optimizer import HipSearchOptimizer
+    rng = np.random.default_rng(8)
+    d = 64
+    opt = HipSearchOptimizer(SearchConfig(dimension=d, metric=MetricType.COSINE, collection_name="dups"))
+    base = _unit(rng, 40, d)
+    opt.upsert(base, [{"chunk_id": f"b{i}", "document_id": 1, "text": "base"} for i in range(40)], [f"b{i}" for i in range(40)])
+    v = _unit(rng, 3, d)
+    opt.upsert(v, [{"chunk_id": "x", "document_id": 1, "text": "first"}, {"chunk_id": "y", "document_id": 1, "text": "y"},
+                   {"chunk_id": "x", "document_id": 1, "text": "second"}], ["x", "y", "x"])
+    assert run(opt.get_vector_count()) == 42
+    for q in (v[0], v[2]):
+        hits = run(opt.search(q.tolist(), limit=42, min_score=-1.0))
+        texts = [c.text for c, _s in hits if c.chunk_id == "x"]
+        assert texts == ["second"]
+    assert opt.get_vector("x")["payload"]["text"] == "second"
+    with pytest.raises(SearchError):
+        run(opt.search(v[0].tolist(), limit=2000))
+    run(opt.delete_collection())

@@ -165,3 +165,56 @@ def test_mmr_on_rows_of_an_ivf_index():
     assert mmr_select_rows(idx, tail, rel, 0.5, 0.7, "cosine", 12) == want
     check(n)
     idx.close()
+
+
+def test_ivf_snapshot_round_trip(tmp_path):
+    """rag_index_save / rag_index_load on an IVF index: centroids, every row's list, rows in insertion
+    order, ids and soft deletes come back; searches answer bit for bit as before (nothing is
+    re-assigned on load), also with rows still waiting unpacked at the tail."""
+    from rag_amd import DeviceIndex, RagHipError
+    rng = np.random.default_rng(77)
+    for metric, d in (("ip", 128), ("cosine", 100)):
+        n, nlist, nprobe, k = 20_000, 64, 8, 10
+        X = (_unit(rng, n, d) * rng.uniform(0.5, 2.0, (n, 1))).astype(np.float32)
+        Q = _unit(rng, 70, d)
+        C = _unit(rng, nlist, d)
+        ids = (np.arange(n, dtype=np.int64) * 3 + 11)
+        idx = DeviceIndex(d, metric=metric, kind="ivf")
+        idx.train_ivf(nlist, centroids=C)
+        idx.add(X[:15_000], ids=ids[:15_000])
+        idx.search(Q[:2], k, nprobe=nprobe)                      # packs the first rows
+        idx.add(X[15_000:], ids=ids[15_000:])                    # these wait at the tail
+        idx.set_active(list(range(100, 160)), False)
+        path = str(tmp_path / f"ivf_{metric}.bin")
+        idx.save(path)
+        before1 = idx.search(Q[:3], k, nprobe=nprobe)
+        before = idx.search(Q, k, nprobe=nprobe)
+        back = DeviceIndex.load(path)
+        assert (back.kind, back.metric, back.dim, len(back)) == ("ivf", metric, d, n)
+        after1 = back.search(Q[:3], k, nprobe=nprobe)
+        assert back.last_path == "ivf"
+        after = back.search(Q, k, nprobe=nprobe)
+        assert back.last_path == idx.last_path
+        for (Db, Ib), (Da, Ia) in ((before1, after1), (before, after)):
+            assert np.array_equal(Ib, Ia) and np.array_equal(Db, Da)
+        assert not np.isin(ids[100:160], after[1]).any()
+        rows = rng.integers(0, n, 50)
+        assert np.array_equal(idx.reconstruct(rows), back.reconstruct(rows))
+        # the restored index keeps growing like any other
+        extra = _unit(rng, 500, d)
+        back.add(extra, ids=np.arange(500, dtype=np.int64) + 10_000_000)
+        idx.add(extra, ids=np.arange(500, dtype=np.int64) + 10_000_000)
+        a, b = back.search(Q, k, nprobe=nprobe), idx.search(Q, k, nprobe=nprobe)
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])
+        idx.close()
+        back.close()
+    # a damaged header is refused
+    raw = bytearray(open(path, "rb").read())
+    raw[12:16] = (7).to_bytes(4, "little")                       # metric field
+    bad = str(tmp_path / "bad.bin")
+    open(bad, "wb").write(bytes(raw))
+    with pytest.raises(RagHipError):
+        DeviceIndex.load(bad)
+    open(bad, "wb").write(bytes(raw[: len(raw) // 2]))
+    with pytest.raises(RagHipError):
+        DeviceIndex.load(bad)

@@ -230,3 +230,46 @@ def test_pooled_manager_compacts_after_deletes():
     assert np.allclose([h["score"] for h in after], [h["score"] for h in before], rtol=1e-6, atol=1e-7)
     assert run(mgr.get_vector_by_chunk_id("doc_3_chunk_5"))["source"] == "doc_3_content"
     run(mgr.cleanup())
+
+
+def test_pool_backup_restore_and_last_duplicate_wins(tmp_path):
+    from rag_amd.pooled import PooledCollections
+    rng = np.random.default_rng(91)
+    d = 96
+    pool = PooledCollections(d, metric="cosine")
+    names = []
+    for c in range(6):
+        n = int(rng.integers(30, 120))
+        ids = [f"c{c}_{i}" for i in range(n)]
+        pool.upsert(f"c{c}", _unit(rng, n, d), [{"chunk_id": i, "document_id": c} for i in ids], ids)
+        names.append(f"c{c}")
+    # one batch that names the same point twice: the later vector and payload win, the earlier row is hidden
+    twice = _unit(rng, 3, d)
+    pool.upsert("c2", twice, [{"chunk_id": "dup", "v": 1}, {"chunk_id": "other", "v": 1}, {"chunk_id": "dup", "v": 2}],
+                ["dup", "other", "dup"])
+    hits = pool.search_many(["c2"], twice[[0, 2]], 5, min_score=-1.0)
+    for qi in range(2):
+        got = [(pool.payloads[r]["chunk_id"], pool.payloads[r].get("v")) for r, _s in hits[qi][0]]
+        assert ("dup", 1) not in got                        # not even for its own vector
+    assert got[0] == ("dup", 2)
+    assert pool.dead_rows() == 1
+    pool.set_collection_active("c4", False)
+    pool.drop("c1")
+    Q = _unit(rng, 3, d)
+
+    def answers(p):
+        out = p.search_many(names, Q, 6, min_score=-1.0)
+        return [[[(p.payloads[r]["chunk_id"], s) for r, s in per] for per in qh] for qh in out]
+
+    before = answers(pool)
+    path = str(tmp_path / "pool.bin")
+    info = pool.backup(path)
+    assert info["collections"] == 5
+    back = PooledCollections.restore(path)
+    assert answers(back) == before
+    assert back.count("c2") == pool.count("c2") and back.row_of("c2", "dup") == pool.row_of("c2", "dup")
+    back.set_collection_active("c4", True)
+    assert len(back.search_many(["c4"], Q, 6, min_score=-1.0)[0][0]) == 6
+    assert back.compact() == pool.dead_rows()                    # a restored pool vacuums like the original
+    back.close()
+    pool.close()
