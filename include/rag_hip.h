@@ -96,8 +96,10 @@ int rag_index_set_active(rag_index_t* h, int64_t n, const int64_t* rows, int act
 int rag_index_reconstruct(rag_index_t* h, int64_t n, const int64_t* rows, float* out);
 
 /* vector_db/qdrant_client.py:475-621 backup_collection / :623-764 restore_collection:
- * a binary snapshot of a FLAT index (header, fp32 rows, ids, soft-delete bytes) in
- * place of the reference's JSON list-of-floats file.  Payloads stay with the caller. */
+ * a binary snapshot (header, fp32 rows in insertion order, ids, soft-delete bytes; an IVF index
+ * adds its centroids and the list of every row, and comes back with those lists -- nothing is
+ * re-assigned on load) in place of the reference's JSON list-of-floats file.  Payloads stay
+ * with the caller. */
 int rag_index_save(rag_index_t* h, const char* path);
 int rag_index_load(const char* path, int device, rag_index_t** out);
 
@@ -202,6 +204,32 @@ int rag_mmr_select(int64_t n, int d, const void* emb, int emb_is_f64, const doub
 int rag_mmr_select_rows(rag_index_t* h, int64_t n, const int64_t* rows, const double* rel,
                         double lambda, double similarity_threshold, int metric,
                         int max_results, int32_t* out_idx, int32_t* n_out);
+
+/* ---- one index over several GPUs of this process ---------------------------------------
+ * The reference's server is ONE process per worker and its search call blocks in it
+ * (vector_db/search_optimizer.py:213-222, vector_db/storage_manager.py:427-511): a caller like
+ * that, or any non-Python program, cannot join a torch.distributed world.  rag_multi_* gives it
+ * the row-sharded index inside the process: rows of every add are dealt over the devices in
+ * contiguous parts, a search runs on all devices at once (one host thread per device) and the
+ * per-device answers are merged under the library's order rule (score descending, ties to the
+ * lower id).  Same arguments and results as the rag_index_* call of the same name; ids == NULL
+ * numbers the rows 0, 1, 2, ... in the order they were added, as a single index would.
+ * device_ids may name a device more than once (two shards on one GPU). */
+typedef struct rag_multi rag_multi_t;
+int rag_multi_create(int dim, int metric, int kind, int n_devices, const int* device_ids, rag_multi_t** out);
+int rag_multi_free(rag_multi_t* h);
+int64_t rag_multi_ntotal(const rag_multi_t* h);
+int rag_multi_ndevices(const rag_multi_t* h);
+/* rows held by shard s (0 <= s < ndevices) */
+int64_t rag_multi_shard_rows(const rag_multi_t* h, int s);
+int rag_multi_train_ivf(rag_multi_t* h, int nlist, const float* centroids, int64_t nsample, const float* sample);
+int rag_multi_add(rag_multi_t* h, int64_t n, const float* x, const int64_t* ids);
+int rag_multi_set_prefilter(rag_multi_t* h, int mode);
+/* rows[] / row_mask count rows in the order they were added, over all devices */
+int rag_multi_set_active(rag_multi_t* h, int64_t n, const int64_t* rows, int active);
+int rag_multi_reconstruct(rag_multi_t* h, int64_t n, const int64_t* rows, float* out);
+int rag_multi_search(rag_multi_t* h, int64_t nq, const float* q, int k, float min_score, int nprobe,
+                     const uint8_t* row_mask, float* D, int64_t* I);
 
 /* ---- keyword side: BM25 over a token-id corpus in device memory -----------------------
  * vector_db/search_manager.py:142-180 (CorpusStatsManager.calculate_bm25_score), :182-263

@@ -67,6 +67,17 @@ SIGNATURES = {
                                     _i32, _vp]),
     "rag_index_hybrid_mmr_device": (_i32, [_vp, _vp, _i32, _f32, _i32, _vp, _i64, _vp, _vp, _f64, _f64, _i32, _f64, _f64,
                                            _i32, _i32, _vp, _vp]),
+    "rag_multi_create": (_i32, [_i32, _i32, _i32, _i32, _vp, C.POINTER(_vp)]),
+    "rag_multi_free": (_i32, [_vp]),
+    "rag_multi_ntotal": (_i64, [_vp]),
+    "rag_multi_ndevices": (_i32, [_vp]),
+    "rag_multi_shard_rows": (_i64, [_vp, _i32]),
+    "rag_multi_train_ivf": (_i32, [_vp, _i32, _vp, _i64, _vp]),
+    "rag_multi_add": (_i32, [_vp, _i64, _vp, _vp]),
+    "rag_multi_set_prefilter": (_i32, [_vp, _i32]),
+    "rag_multi_set_active": (_i32, [_vp, _i64, _vp, _i32]),
+    "rag_multi_reconstruct": (_i32, [_vp, _i64, _vp, _vp]),
+    "rag_multi_search": (_i32, [_vp, _i64, _vp, _i32, _f32, _i32, _vp, _vp, _vp]),
     "rag_bm25_create": (_i32, [_i32, C.POINTER(_vp)]),
     "rag_bm25_destroy": (None, [_vp]),
     "rag_bm25_ndocs": (_i64, [_vp]),

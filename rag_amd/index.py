@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import Optional, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -265,6 +265,91 @@ class DeviceIndex:
 
 
 _MMR_METRICS = {"cosine": _lib.MMR_COSINE, "dot_product": _lib.MMR_DOT, "euclidean": _lib.MMR_EUCLIDEAN}
+
+
+class MultiDeviceIndex:
+    """One index over several GPUs of this process (``rag_multi_*``): rows of every ``add`` are
+    dealt over the devices, a search runs on all of them at once and the answers are merged.
+    For callers without a process group -- the reference's server answers a search with a
+    blocking call inside one worker process (vector_db/search_optimizer.py:213-222).
+    ``devices`` may name a GPU more than once.  numpy in, numpy out, like ``DeviceIndex.search``."""
+
+    def __init__(self, dim: int, devices: Sequence[int], metric: str = "ip", kind: str = "flat"):
+        metrics = {"ip": _lib.METRIC_IP, "dot": _lib.METRIC_IP, "cosine": _lib.METRIC_COSINE}
+        kinds = {"flat": _lib.KIND_FLAT, "ivf": _lib.KIND_IVF}
+        if metric not in metrics or kind not in kinds:
+            raise ValueError(f"unknown metric {metric!r} or index kind {kind!r}")
+        self.dim, self.metric, self.kind = int(dim), metric, kind
+        self.devices = [int(d) for d in devices]
+        ids = (C.c_int * len(self.devices))(*self.devices)
+        self._h = C.c_void_p()
+        check(lib.rag_multi_create(self.dim, metrics[metric], kinds[kind], len(self.devices), ids, C.byref(self._h)))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib.rag_multi_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self) -> int:
+        return int(lib.rag_multi_ntotal(self._h))
+
+    def shard_rows(self) -> List[int]:
+        return [int(lib.rag_multi_shard_rows(self._h, s)) for s in range(len(self.devices))]
+
+    def set_prefilter(self, enabled: bool) -> None:
+        check(lib.rag_multi_set_prefilter(self._h, 1 if enabled else 0))
+
+    def train_ivf(self, nlist: int, centroids=None, sample=None) -> None:
+        c = None if centroids is None else np.ascontiguousarray(centroids, dtype=np.float32)
+        s = None if sample is None else np.ascontiguousarray(sample, dtype=np.float32)
+        if c is not None and c.shape != (nlist, self.dim):
+            raise ValueError("centroids must be [nlist, dim]")
+        check(lib.rag_multi_train_ivf(self._h, int(nlist), _ptr(c), 0 if s is None else s.shape[0], _ptr(s)))
+
+    def add(self, x, ids=None) -> None:
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.ndim != 2 or x.shape[1] != self.dim:
+            raise ValueError(f"expected float32 [n, {self.dim}] array, got {x.shape}")
+        ids_np = None if ids is None else np.ascontiguousarray(ids, dtype=np.int64)
+        if ids_np is not None and ids_np.shape != (x.shape[0],):
+            raise ValueError("ids must have one entry per row")
+        check(lib.rag_multi_add(self._h, x.shape[0], _ptr(x), _ptr(ids_np)))
+
+    def set_active(self, rows, active: bool) -> None:
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        check(lib.rag_multi_set_active(self._h, rows.size, _ptr(rows), 1 if active else 0))
+
+    def reconstruct(self, rows) -> np.ndarray:
+        rows = np.ascontiguousarray(rows, dtype=np.int64).reshape(-1)
+        out = np.empty((rows.size, self.dim), dtype=np.float32)
+        check(lib.rag_multi_reconstruct(self._h, rows.size, _ptr(rows), _ptr(out)))
+        return out
+
+    def search(self, q, k: int, min_score: Optional[float] = None, nprobe: int = 1, row_mask=None):
+        k = int(k)
+        if not 1 <= k <= MAX_K:
+            raise ValueError(f"k must be in [1, {MAX_K}]")
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        if q.ndim != 2 or q.shape[1] != self.dim:
+            raise ValueError(f"expected float32 [nq, {self.dim}] array, got {q.shape}")
+        m = None
+        if row_mask is not None:
+            m = np.ascontiguousarray(row_mask, dtype=np.uint8).reshape(-1)
+            if m.size != len(self):
+                raise ValueError("row_mask must have one byte per row")
+        D = np.full((q.shape[0], k), -FLT_MAX, dtype=np.float32)
+        I = np.full((q.shape[0], k), -1, dtype=np.int64)
+        ms = -FLT_MAX if min_score is None else float(min_score)
+        check(lib.rag_multi_search(self._h, q.shape[0], _ptr(q), k, ms, int(nprobe), _ptr(m), _ptr(D), _ptr(I)))
+        return D, I
 
 
 def hybrid_mmr(index: "DeviceIndex", q, topn: int, bm25_rows, bm25_scores, *, fuse_limit: Optional[int] = None,

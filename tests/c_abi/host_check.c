@@ -2,7 +2,8 @@
  * A host program in plain C against include/rag_hip.h: what a non-Python caller
  * (a cgo / JNI / C++ host) does with the library.  Builds a small corpus, checks
  * rag_index_search against a brute-force loop, exercises segments, soft delete,
- * reconstruct, the IVF entry points, score fusion, MMR and the error convention.
+ * reconstruct, the IVF entry points, score fusion, MMR, the several-devices index, the keyword
+ * scorer and the error convention.
  * Exit code 0 = every check passed; prints the first failure otherwise.
  *
  *   gcc -O2 -std=c11 -I include tests/c_abi/host_check.c -o tests/c_abi/host_check \
@@ -159,6 +160,64 @@ int main(void) {
     CHECK(rag_fuse_weighted(4, a, b, 0.7, 0.3, 1, 0.2, 3, order, out, &nout) == RAG_OK, "fuse");
     CHECK(nout == 3 && order[0] == 0 && order[1] == 1 && order[2] == 3, "fusion order");
     CHECK(out[0] == 0.9 * 0.7 + 0.0 * 0.3 && out[1] == 0.5 * 0.7 + 0.8 * 0.3 && out[2] == 0.0 * 0.7 + 0.4 * 0.3, "fusion scores");
+
+    /* one index over several devices of this process (here: three shards on device 0) */
+    {
+        rag_multi_t* m = NULL;
+        int devs[3] = {0, 0, 0};
+        CHECK(rag_multi_create(d, RAG_METRIC_IP, RAG_KIND_FLAT, 0, devs, &m) == RAG_ERR_INVALID && m == NULL, "0 devices accepted");
+        CHECK(rag_multi_create(d, RAG_METRIC_IP, RAG_KIND_FLAT, 3, devs, &m) == RAG_OK && m, "multi create");
+        CHECK(rag_multi_add(m, 7001, X, NULL) == RAG_OK, "multi add 1");
+        CHECK(rag_multi_add(m, n - 7001, X + (size_t)7001 * d, NULL) == RAG_OK, "multi add 2");
+        CHECK(rag_multi_ntotal(m) == n && rag_multi_ndevices(m) == 3, "multi ntotal");
+        CHECK(rag_multi_shard_rows(m, 0) + rag_multi_shard_rows(m, 1) + rag_multi_shard_rows(m, 2) == n, "shard rows");
+        CHECK(rag_multi_search(m, nq, Q, k, -FLT_MAX, 1, NULL, D, I) == RAG_OK, "multi search");
+        for (int qi = 0; qi < nq; ++qi) {
+            brute(X, n, d, Q + (size_t)qi * d, 0, n, NULL, -FLT_MAX, k, Dr, Ir);
+            CHECK(same_hits(D + qi * k, I + qi * k, Dr, Ir, k), "multi query %d differs from the brute-force scan", qi);
+        }
+        CHECK(rag_multi_search(m, 1, Q, k, 1.0f, 1, mask, D, I) == RAG_OK, "multi masked search");
+        brute(X, n, d, Q, 0, n, mask, 1.0f, k, Dr, Ir);
+        CHECK(same_hits(D, I, Dr, Ir, k), "multi masked query differs");
+        brute(X, n, d, Q, 0, n, NULL, -FLT_MAX, k, Dr, Ir);
+        best = Ir[0];
+        CHECK(rag_multi_set_active(m, 1, &best, 0) == RAG_OK, "multi set_active");
+        CHECK(rag_multi_search(m, 1, Q, k, -FLT_MAX, 1, NULL, D, I) == RAG_OK && I[0] == Ir[1], "multi hidden row returned");
+        int64_t mrows[3] = {3, 7001, 19999};
+        float mback[3 * 128];
+        CHECK(rag_multi_reconstruct(m, 3, mrows, mback) == RAG_OK, "multi reconstruct");
+        for (int j = 0; j < 3; ++j)
+            CHECK(memcmp(mback + j * d, X + (size_t)mrows[j] * d, d * sizeof(float)) == 0, "multi reconstructed row %d differs", j);
+        mrows[0] = n;
+        CHECK(rag_multi_reconstruct(m, 1, mrows, mback) == RAG_ERR_INVALID, "row out of range accepted");
+        CHECK(rag_multi_free(m) == RAG_OK, "multi free");
+    }
+
+    /* keyword side: BM25 over token ids, ranking */
+    {
+        rag_bm25_t* kw = NULL;
+        CHECK(rag_bm25_create(0, &kw) == RAG_OK && kw, "bm25 create");
+        /* three documents: [5 5 7 9 2], [1 1 1], [] */
+        int64_t dlen[3] = {5, 3, 0};
+        int32_t toks[8] = {5, 5, 7, 9, 2, 1, 1, 1};
+        CHECK(rag_bm25_add(kw, 3, dlen, toks) == RAG_OK && rag_bm25_ndocs(kw) == 3, "bm25 add");
+        int32_t terms[2] = {5, 7};
+        double idf[2] = {1.2, 0.7}, raw[3];
+        CHECK(rag_bm25_score(kw, 3, NULL, 2, terms, idf, 5.0, 1.5, 0.75, raw) == RAG_OK, "bm25 score");
+        /* vector_db/search_manager.py:171-176 with f = 2 and 1, dl = avgdl = 5 */
+        double len = 1.5 * (1 - 0.75 + 0.75 * (5.0 / 5.0));
+        double want = 0.0;
+        want += 1.2 * ((2 * (1.5 + 1)) / (2 + len));
+        want += 0.7 * ((1 * (1.5 + 1)) / (1 + len));
+        CHECK(raw[0] == want && raw[1] == 0.0 && raw[2] == 0.0, "bm25 scores %.17g vs %.17g", raw[0], want);
+        int64_t krows[2];
+        double knorm[2], kraw[2];
+        int32_t kn = 0;
+        CHECK(rag_bm25_rank(kw, 3, NULL, 2, terms, idf, 5.0, 1.5, 0.75, 1, 0.5, 2, krows, knorm, kraw, &kn) == RAG_OK, "bm25 rank");
+        CHECK(kn == 1 && krows[0] == 0 && knorm[0] == 1.0 && kraw[0] == want && krows[1] == -1, "bm25 ranking");
+        CHECK(rag_bm25_score(kw, 3, NULL, 2, terms, idf, 0.0, 1.5, 0.75, raw) == RAG_ERR_INVALID, "avgdl 0 accepted");
+        rag_bm25_destroy(kw);
+    }
 
     free(X);
     free(Q);
