@@ -42,7 +42,17 @@ int merge_cap(long long per_query, int k);
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f4acc __attribute__((ext_vector_type(4)));
 
-constexpr int NR_WAVES = 8;            // waves per workgroup (2 per SIMD), one workgroup per CU
+#ifndef RAG_NARROW_WAVES
+#define RAG_NARROW_WAVES 8
+#endif
+// K steps per register set where a row holds a multiple of 8 steps, per query-block width (measurement knob)
+#ifndef RAG_NARROW_DEPTH1
+#define RAG_NARROW_DEPTH1 2
+#endif
+#ifndef RAG_NARROW_DEPTH2
+#define RAG_NARROW_DEPTH2 2
+#endif
+constexpr int NR_WAVES = RAG_NARROW_WAVES;   // waves per workgroup (NR_WAVES / 4 per SIMD), one workgroup per CU
 constexpr int NR_TILE = 32;            // corpus rows per wave step (two 16-row MFMA row groups)
 constexpr int NR_TRIG = 32;            // compact a candidate buffer once it holds more keys than this
 constexpr int NR_CAP = NR_TRIG + NR_TILE;   // 64: one key per lane when sorted
@@ -83,7 +93,7 @@ struct AChunk {
 // while one set feeds the MFMAs, the loads of the next NSETS - 1 groups are outstanding.  The number of
 // groups per row (ld / (16 * DEPTH)) is a multiple of NSETS, so every tile starts with the same rotation.
 template <int NJ, int DEPTH, int NSETS>
-__global__ __launch_bounds__(NR_WAVES * 64, 2) void narrow_topk_kernel(NarrowArgs a) {
+__global__ __launch_bounds__(NR_WAVES * 64, NR_WAVES / 4) void narrow_topk_kernel(NarrowArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (a.run_if && *a.run_if == 0) return;
     constexpr int NQB = NJ * 16;                        // queries of the block
@@ -391,7 +401,7 @@ static NarrowPlan narrow_plan(const rag_index* h, long long nq, int k) {
     static const int sample_on = env_int_n("RAG_NARROW_SAMPLE", 1);     // measurement only
     NarrowPlan p = {};
     p.sample = (sample_on && h->n >= 32 * NR_SAMPLE_ROWS) ? NR_SAMPLE_ROWS : 0;
-    p.grid_s = p.sample ? (int)(p.sample / (NR_TILE * NR_WAVES)) : 0;
+    p.grid_s = p.sample ? (int)((p.sample + NR_TILE * NR_WAVES - 1) / (NR_TILE * NR_WAVES)) : 0;
     p.grid_m = narrow_grid(h->n - p.sample);
     p.Ws = (long long)p.grid_s * NR_WAVES;
     p.Wm = (long long)p.grid_m * NR_WAVES;
@@ -431,8 +441,8 @@ static int launch_narrow(const NarrowArgs& a, int grid, size_t lds, int device, 
 static int launch_narrow_shape(const NarrowArgs& a, int nj, int grid, size_t lds, int device, hipStream_t s) {
     // 4 register sets of 2 K steps where a row holds a multiple of 8 steps (ld % 256 == 0), of 1 step otherwise
     const bool wide = (a.ld % 256) == 0;
-    if (nj == 1) return wide ? launch_narrow<1, 2, 4>(a, grid, lds, device, s) : launch_narrow<1, 1, 4>(a, grid, lds, device, s);
-    return wide ? launch_narrow<2, 2, 4>(a, grid, lds, device, s) : launch_narrow<2, 1, 4>(a, grid, lds, device, s);
+    if (nj == 1) return wide ? launch_narrow<1, RAG_NARROW_DEPTH1, 4>(a, grid, lds, device, s) : launch_narrow<1, 1, 4>(a, grid, lds, device, s);
+    return wide ? launch_narrow<2, RAG_NARROW_DEPTH2, 4>(a, grid, lds, device, s) : launch_narrow<2, 1, 4>(a, grid, lds, device, s);
 }
 
 // qbuf: padded queries; the caller has sized h->ws with narrow_topk_workspace() behind them
