@@ -277,8 +277,16 @@ __global__ __launch_bounds__(256) void mmr_simmat_kernel(const double* En, const
                                                          double* S, int ldS) {
     const int n = n_dev ? *n_dev : n_max;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c0 = blockIdx.x * SIM_TC + wave * 2;
-    const int s0 = blockIdx.y * SIM_TS;
+    // the matrix is symmetric bit for bit (a product and a squared difference do not depend on the order of
+    // their operands, and both orders run the same chain and the same reduction tree): workgroup i computes tile
+    // (bx, by), by <= bx, of the lower triangle and stores every value at (c, s) and at (s, c)
+    int bx = (int)((sqrtf(8.f * (float)blockIdx.x + 1.f) - 1.f) * 0.5f);
+    while ((bx + 1) * (bx + 2) / 2 <= (int)blockIdx.x) ++bx;
+    while (bx * (bx + 1) / 2 > (int)blockIdx.x) --bx;
+    const int by = (int)blockIdx.x - bx * (bx + 1) / 2;
+    const int c0 = bx * SIM_TC + wave * 2;
+    const int s0 = by * SIM_TS;
+    const bool mirror = bx != by;
     if (c0 >= n || s0 >= n) return;
     const int c1 = c0 + 1 < n ? c0 + 1 : c0;
     const double* e0 = En + (size_t)c0 * d;
@@ -321,7 +329,11 @@ __global__ __launch_bounds__(256) void mmr_simmat_kernel(const double* En, const
             if (metric == RAG_MMR_EUCLIDEAN) { a0 = 1.0 / (1.0 + sqrt(a0)); a1 = 1.0 / (1.0 + sqrt(a1)); }
             if (lane == 0 && s0 + si < n) {
                 S[(size_t)c0 * ldS + sr] = a0;
-                if (c0 + 1 < n) S[(size_t)(c0 + 1) * ldS + sr] = a1;
+                if (mirror) S[(size_t)sr * ldS + c0] = a0;
+                if (c0 + 1 < n) {
+                    S[(size_t)(c0 + 1) * ldS + sr] = a1;
+                    if (mirror) S[(size_t)sr * ldS + c0 + 1] = a1;
+                }
             }
         }
     } else {
@@ -351,7 +363,11 @@ __global__ __launch_bounds__(256) void mmr_simmat_kernel(const double* En, const
             if (metric == RAG_MMR_EUCLIDEAN) { a0 = 1.0 / (1.0 + sqrt(a0)); a1 = 1.0 / (1.0 + sqrt(a1)); }
             if (lane == 0) {
                 S[(size_t)c0 * ldS + sr] = a0;
-                if (c0 + 1 < n) S[(size_t)(c0 + 1) * ldS + sr] = a1;
+                if (mirror) S[(size_t)sr * ldS + c0] = a0;
+                if (c0 + 1 < n) {
+                    S[(size_t)(c0 + 1) * ldS + sr] = a1;
+                    if (mirror) S[(size_t)sr * ldS + c0 + 1] = a1;
+                }
             }
         }
     }
@@ -712,7 +728,9 @@ static int mmr_sim_limit() {
 static int enqueue_mmr_sim(const MmrArgs& p, int n_max, double* S, MmrSelArgs sel, hipStream_t s) {
     MmrState none = {};
     hipLaunchKernelGGL(mmr_prepare_kernel, dim3((unsigned)n_max), dim3(64), 0, s, p, none);
-    const dim3 grid((n_max + SIM_TC - 1) / SIM_TC, (n_max + SIM_TS - 1) / SIM_TS);
+    static_assert(SIM_TC == SIM_TS, "square tiles: the lower triangle is enumerated tile by tile");
+    const int tiles = (n_max + SIM_TC - 1) / SIM_TC;
+    const dim3 grid((unsigned)(tiles * (tiles + 1) / 2));
     const int jl = (p.d + 63) / 64;
     if (jl <= 4) hipLaunchKernelGGL(mmr_simmat_kernel<4>, grid, dim3(256), 0, s, p.En, p.n_dev, n_max, p.d, p.metric, S, n_max);
     else if (jl <= 8) hipLaunchKernelGGL(mmr_simmat_kernel<8>, grid, dim3(256), 0, s, p.En, p.n_dev, n_max, p.d, p.metric, S, n_max);
