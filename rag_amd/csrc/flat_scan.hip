@@ -349,6 +349,7 @@ __device__ __forceinline__ void finalise_hit(const MergeArgs& a, long long q, in
 // per query).  Keys stream through an LDS buffer: a key is appended only if it
 // beats the current k-th key; the buffer is bitonic-sorted and cut to k when it
 // cannot take another 1024 keys.
+RAG_STAMPS_DEFINE(merge)
 __global__ __launch_bounds__(1024) void merge_keys_kernel(MergeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64* buf = reinterpret_cast<u64*>(smem);
@@ -367,50 +368,100 @@ __global__ __launch_bounds__(1024) void merge_keys_kernel(MergeArgs a) {
     // it matter: each thread walks its runs from the head and stops at the first key below.
     const long long P = a.per_query / k;
     if (a.fast_cap > 0 && P >= k && P <= cap && P * k == a.per_query) {
-        // both selections are done by counting, not sorting: keys are distinct (the row sits in the low
-        // bits), so "the number of keys above mine" is a rank, and a count over an LDS array read by
-        // every lane at the same address (a broadcast) needs no barrier between its steps
         const int Pn = (int)P;
-        // a lower bound of the answer's k-th key from the run heads: deal the heads into k groups; the
-        // group maxima are k distinct keys, so their minimum has k keys at or above it
-        u64* gmax = cand;                                   // [k], before cand is filled
-        for (int i = tid; i < k; i += 1024) gmax[i] = KEY_EMPTY;
-        if (tid == 0) { *s_cnt = 0; *s_thr = ~0ull; }
+        RAG_STAMP(0);
+        // a lower bound of the answer's k-th key from the run heads: any value with k heads at or above it.
+        // The heads (thousands when every wave of the scan hands over a run) are binned over their own range
+        // into 1024 buckets; the lower edge of the bucket in which the count from the top reaches k is within
+        // 1/1024 of the range of the k-th largest head itself -- a few hundred keys are then left to rank, where
+        // the minimum over k groups of heads left thousands and an exact rank of the heads costs P^2 compares
+        int* hist = reinterpret_cast<int*>(cand);               // [1024], before cand is filled
+        u64* s_lo = s_thr;                                      // the smallest head lives in *s_thr until the bound replaces it
+        u64* s_hi = cand + 512;                                 // behind the histogram
+        for (int i = tid; i < 1024; i += 1024) hist[i] = 0;
+        if (tid == 0) { *s_cnt = 0; *s_lo = ~0ull; *s_hi = 0ull; }
         __syncthreads();
-        for (int i = tid; i < Pn; i += 1024) {
-            const u64 hd = in[(size_t)i * k];
-            buf[i] = hd;
-            atomicMax(&gmax[i % k], hd);
-        }
-        __syncthreads();
-        for (int i = tid; i < k; i += 1024) atomicMin(s_thr, gmax[i]);
-        __syncthreads();
-        if (*s_thr == KEY_EMPTY) {
-            // a group without a key (masked or short row ranges): the exact k-th largest head instead
-            __syncthreads();
+        {
+            // range of the heads: reduced inside each wave first (thousands of LDS atomics on one address
+            // would run one after the other: 19 us for 2048 heads)
+            u64 mn = ~0ull, mx = 0ull;
             for (int i = tid; i < Pn; i += 1024) {
-                const u64 mine = buf[i];
-                if (mine == KEY_EMPTY) continue;
-                int above = 0;
-#pragma unroll 8
-                for (int j = 0; j < Pn; ++j) above += buf[j] > mine ? 1 : 0;
-                if (above == k - 1) *s_thr = mine;
+                const u64 hd = in[(size_t)i * k];
+                buf[i] = hd;
+                if (hd != KEY_EMPTY) { mn = hd < mn ? hd : mn; mx = hd > mx ? hd : mx; }
             }
-            __syncthreads();
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const u64 omn = shfl_xor_u64(mn, off), omx = shfl_xor_u64(mx, off);
+                mn = omn < mn ? omn : mn;
+                mx = omx > mx ? omx : mx;
+            }
+            if ((tid & 63) == 0 && mx != 0ull) { atomicMin(s_lo, mn); atomicMax(s_hi, mx); }
         }
+        __syncthreads();
+        RAG_STAMP(1);
+        const u64 lo = *s_lo, hi = *s_hi;
+        const int shift = (hi > lo) ? max(0, 64 - __clzll((long long)(hi - lo)) - 10) : 0;      // (hi - lo) >> shift < 1024
+        __syncthreads();
+        if (hi >= lo)
+            for (int i = tid; i < Pn; i += 1024)
+                if (buf[i] != KEY_EMPTY) atomicAdd(&hist[(int)((buf[i] - lo) >> shift)], 1);
+        if (tid == 0) *s_thr = KEY_EMPTY;
+        __syncthreads();
+        if (tid < 64 && hi >= lo) {
+            // wave 0: lane l owns buckets 16 l .. 16 l + 15.  suf = heads in the buckets of lanes >= l (suffix scan),
+            // the lane in which the count from the top reaches k walks its own 16 buckets downwards
+            int own = 0;
+#pragma unroll
+            for (int b2 = 0; b2 < 16; ++b2) own += hist[tid * 16 + b2];
+            int suf = own;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int up = __shfl_down(suf, off, 64);
+                if (tid + off < 64) suf += up;
+            }
+            const int higher = suf - own;                       // heads in the buckets of the lanes above
+            if (higher < k && suf >= k) {
+                int cnt = higher, b2 = 15;
+                for (; b2 >= 0; --b2) {
+                    cnt += hist[tid * 16 + b2];
+                    if (cnt >= k) break;
+                }
+                *s_thr = lo + ((u64)(tid * 16 + b2) << shift);  // every key at or above it falls in this bucket or a higher one
+            }
+        }
+        __syncthreads();
+        RAG_STAMP(2);
         const u64 bound = *s_thr;
         if (bound != KEY_EMPTY) {
-            for (long long p = tid; p < P; p += 1024) {
-                for (int j = 0; j < k; ++j) {
-                    const u64 key = in[(size_t)p * k + j];
-                    if (key < bound) break;
-                    const int pos = atomicAdd(s_cnt, 1);
-                    if (pos < a.fast_cap) cand[pos] = key;
+            // a run is walked four keys at a time (four independent loads, one memory latency), its head
+            // taken from LDS
+            for (int p = tid; p < Pn; p += 1024) {
+                if (buf[p] < bound) continue;
+                const u64* run = in + (size_t)p * k;
+                bool more = true;
+                for (int j0 = 0; j0 < k && more; j0 += 4) {
+                    u64 key[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) key[j] = j0 + j < k ? run[j0 + j] : KEY_EMPTY;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (!more || key[j] < bound || key[j] == KEY_EMPTY) { more = false; continue; }
+                        const int pos = atomicAdd(s_cnt, 1);
+                        if (pos < a.fast_cap) cand[pos] = key[j];
+                    }
                 }
             }
             __syncthreads();
+            RAG_STAMP(3);
             const int c = *s_cnt;                        // c >= k: k run heads reach the bound
+#ifdef RAG_STAMPS
+            if (tid == 0) { g_rag_stamps[8] = c; g_rag_stamps[9] = Pn; }
+#endif
             if (c <= a.fast_cap) {
+                // the k best of the c keys by counting, not sorting: keys are distinct (the row sits in the low
+                // bits), so "the number of keys above mine" is a rank, and a count over an LDS array that every
+                // lane reads at the same address (a broadcast) needs no barrier between its steps
                 for (int i = tid; i < c; i += 1024) {
                     const u64 mine = cand[i];
                     int above = 0;
@@ -418,6 +469,7 @@ __global__ __launch_bounds__(1024) void merge_keys_kernel(MergeArgs a) {
                     for (int j = 0; j < c; ++j) above += cand[j] > mine ? 1 : 0;
                     if (above < k) finalise_hit(a, q, above, mine);
                 }
+                RAG_STAMP(4);
                 return;
             }
         }

@@ -21,6 +21,8 @@
 
 namespace rag {
 
+RAG_STAMPS_DEFINE(fuse)
+
 constexpr int FUSE_MAX_N = 4096;
 constexpr int MMR_MAX_N = 4096;
 
@@ -509,81 +511,142 @@ __global__ __launch_bounds__(1024) void hybrid_fuse_kernel(HybridArgs p) {
     int* bm_match = bm_last + p.nb;                                                // [nb]
     int* bm_before = bm_match + p.nb;                                              // [nb]
     unsigned char* c_fl = reinterpret_cast<unsigned char*>(bm_before + p.nb);      // [NC]
+    int* order = reinterpret_cast<int*>(smem + ((reinterpret_cast<size_t>(c_fl + NC) - reinterpret_cast<size_t>(smem) + 3) & ~(size_t)3));   // [NC] candidate at each rank
     if (tid == 0) { s_nsem = 0; s_nbvalid = 0; s_nonly = 0; s_kept = 0; s_maxsem = 0ull; s_maxbm = 0ull; }
+    RAG_STAMP(0);
     __syncthreads();
-    // semantic side
-    for (int i = tid; i < p.topn; i += 1024) {
-        const long long r = p.rows[i];
-        c_fl[i] = 0;
-        c_bm[i] = 0.0;
-        c_row[i] = r;
-        if (r >= 0) {
-            const double sv = (double)p.D[i];
-            c_sem[i] = sv;
-            c_fl[i] = 1;
-            atomicAdd(&s_nsem, 1);
-            atomicMax(&s_maxsem, f64_ordered(sv));
+    const int lane = tid & 63, wave = tid >> 6;
+    // counts and maxima are reduced inside a wave before they touch their LDS word: atomics of a whole
+    // workgroup on one address run one after the other
+    auto wave_max_u64 = [](unsigned long long v) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = shfl_xor_u64(v, off);
+            v = o > v ? o : v;
         }
+        return v;
+    };
+    // semantic side
+    for (int i0 = 0; i0 < p.topn; i0 += 1024) {
+        const int i = i0 + tid;
+        bool hit = false;
+        unsigned long long ord = 0ull;
+        if (i < p.topn) {
+            const long long r = p.rows[i];
+            c_fl[i] = 0;
+            c_bm[i] = 0.0;
+            c_row[i] = r;
+            if (r >= 0) {
+                const double sv = (double)p.D[i];
+                c_sem[i] = sv;
+                c_fl[i] = 1;
+                hit = true;
+                ord = f64_ordered(sv);
+            }
+        }
+        const int cnt = __popcll(__ballot(hit));
+        ord = wave_max_u64(ord);
+        if (lane == 0 && cnt > 0) { atomicAdd(&s_nsem, cnt); atomicMax(&s_maxsem, ord); }
     }
     // keyword side: rows into LDS (an ignored row becomes -1), maxima over every valid entry.
     // bm_first[j] = lowest j2 with the same row, bm_last[j] = highest, bm_match[j] = lowest semantic hit with it
-    for (int j = tid; j < p.nb; j += 1024) {
-        long long r = p.bm_rows[j];
-        if (r >= 0 && r < p.nrows) {
-            atomicAdd(&s_nbvalid, 1);
-            atomicMax(&s_maxbm, f64_ordered(p.bm_scores[j]));
-        } else {
-            r = -1;
+    for (int j0 = 0; j0 < p.nb; j0 += 1024) {
+        const int j = j0 + tid;
+        bool valid = false;
+        unsigned long long ord = 0ull;
+        if (j < p.nb) {
+            long long r = p.bm_rows[j];
+            if (r >= 0 && r < p.nrows) {
+                valid = true;
+                ord = f64_ordered(p.bm_scores[j]);
+            } else {
+                r = -1;
+            }
+            b_row[j] = r;
+            bm_first[j] = j;
+            bm_last[j] = j;
+            bm_match[j] = 0x7FFFFFFF;
+            bm_before[j] = 0;
         }
-        b_row[j] = r;
-        bm_first[j] = j;
-        bm_last[j] = j;
-        bm_match[j] = 0x7FFFFFFF;
-        bm_before[j] = 0;
+        const int cnt = __popcll(__ballot(valid));
+        ord = wave_max_u64(ord);
+        if (lane == 0 && cnt > 0) { atomicAdd(&s_nbvalid, cnt); atomicMax(&s_maxbm, ord); }
     }
     __syncthreads();
+    RAG_STAMP(1);
     const int nsem = s_nsem;
-    // every (keyword hit, keyword hit) and (keyword hit, semantic hit) pair, dealt over the workgroup
-    for (int t = tid; t < p.nb * p.nb; t += 1024) {
-        const int j = t / p.nb, j2 = t % p.nb;
-        if (j2 != j && b_row[j] >= 0 && b_row[j2] == b_row[j]) {
-            if (j2 < j) atomicMin(&bm_first[j], j2);
-            else atomicMax(&bm_last[j], j2);
-        }
-    }
-    for (int t = tid; t < p.nb * nsem; t += 1024) {
-        const int j = t / nsem, i = t % nsem;
-        if (b_row[j] >= 0 && c_row[i] == b_row[j]) atomicMin(&bm_match[j], i);
+    // every (keyword hit, keyword hit) and (keyword hit, semantic hit) pair: a wave takes a keyword hit j, its
+    // lanes the other side; what a wave finds about j it reduces itself (no atomics, no divisions)
+    auto wave_min_i32 = [](int v) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off, 64); v = o < v ? o : v; }
+        return v;
+    };
+    for (int j = wave; j < p.nb; j += 16) {
+        const long long rj = b_row[j];
+        if (rj < 0) continue;                                  // wave-uniform
+        int first = j, last = j, match = 0x7FFFFFFF;
+        for (int j2 = lane; j2 < p.nb; j2 += 64)
+            if (j2 != j && b_row[j2] == rj) {
+                first = j2 < first ? j2 : first;
+                last = j2 > last ? j2 : last;
+            }
+        for (int i = lane; i < nsem; i += 64)
+            if (c_row[i] == rj) match = i < match ? i : match;
+        // a keyword hit seldom repeats or coincides with a semantic hit: the defaults stand unless a lane found one
+        if (__ballot(first != j || last != j || match != 0x7FFFFFFF) == 0ull) continue;
+        first = wave_min_i32(first);
+        last = -wave_min_i32(-last);
+        match = wave_min_i32(match);
+        if (lane == 0) { bm_first[j] = first; bm_last[j] = last; bm_match[j] = match; }
     }
     __syncthreads();
+    RAG_STAMP(2);
     // keyword-only rows keep the order of their first appearance: place = keyword-only firsts before j
-    for (int t = tid; t < p.nb * p.nb; t += 1024) {
-        const int j = t / p.nb, j2 = t % p.nb;
-        if (j2 < j && b_row[j2] >= 0 && bm_first[j2] == j2 && bm_match[j2] == 0x7FFFFFFF) atomicAdd(&bm_before[j], 1);
-    }
-    __syncthreads();
-    for (int j = tid; j < p.nb; j += 1024) {
-        if (b_row[j] < 0 || bm_first[j] != j) continue;
-        const double val = p.bm_scores[bm_last[j]];          // a repeated row keeps the later score
-        int slot = bm_match[j];
-        if (slot == 0x7FFFFFFF) {
-            slot = nsem + bm_before[j];
-            c_row[slot] = b_row[j];
-            c_sem[slot] = 0.0;
-            c_fl[slot] = 0;
-            atomicAdd(&s_nonly, 1);
+    for (int j = wave; j < p.nb; j += 16) {
+        int before = 0;                                        // wave-uniform: counted with ballots
+        for (int j0 = 0; j0 < j; j0 += 64) {
+            const int j2 = j0 + lane;
+            const bool only = j2 < j && b_row[j2] >= 0 && bm_first[j2] == j2 && bm_match[j2] == 0x7FFFFFFF;
+            before += __popcll(__ballot(only));
         }
-        c_bm[slot] = val;
-        c_fl[slot] |= 2;
+        if (lane == 0) bm_before[j] = before;
     }
     __syncthreads();
+    {
+        int only = 0;
+        for (int j = tid; j < p.nb; j += 1024) {
+            if (b_row[j] < 0 || bm_first[j] != j) continue;
+            const double val = p.bm_scores[bm_last[j]];          // a repeated row keeps the later score
+            int slot = bm_match[j];
+            if (slot == 0x7FFFFFFF) {
+                slot = nsem + bm_before[j];
+                c_row[slot] = b_row[j];
+                c_sem[slot] = 0.0;
+                c_fl[slot] = 0;
+                ++only;
+            }
+            c_bm[slot] = val;
+            c_fl[slot] |= 2;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) only += __shfl_xor(only, off, 64);
+        if (lane == 0 && only > 0) atomicAdd(&s_nonly, only);
+    }
+    __syncthreads();
+    RAG_STAMP(3);
     const int ncand = nsem + s_nonly;
     auto unordered = [](unsigned long long o) { return __longlong_as_double((long long)((o >> 63) ? (o & 0x7FFFFFFFFFFFFFFFull) : ~o)); };
     const double max_sem = nsem > 0 ? unordered(s_maxsem) : 1.0;
     const double max_bm = s_nbvalid > 0 ? unordered(s_maxbm) : 1.0;
     const bool zero_div = (nsem > 0 && max_sem == 0.0) || (s_nbvalid > 0 && max_bm == 0.0);
     const int pool = zero_div ? nsem : ncand;
-    for (int i = tid; i < npad; i += 1024) {
+    // up to 1024 slots the stable descending order comes from counting (below) and only the keys are kept;
+    // larger sets are sorted
+    const bool by_rank = npad <= 1024;
+    u64* ek = reinterpret_cast<u64*>(e);                 // [npad] keys (0: not kept), rank path
+    for (int i0 = 0; i0 < npad; i0 += 1024) {
+        const int i = i0 + tid;
         SortEntry en;
         en.key = 0;
         en.idx = 0xFFFFFFFFu;
@@ -604,16 +667,65 @@ __global__ __launch_bounds__(1024) void hybrid_fuse_kernel(HybridArgs p) {
                 en.key = f64_ordered(sc);
                 if (en.key == 0) en.key = 1;
                 en.idx = (uint32_t)i;
-                atomicAdd(&s_kept, 1);
             }
         }
-        e[i] = en;
+        const int cnt = __popcll(__ballot(en.key != 0));
+        if (lane == 0 && cnt > 0) atomicAdd(&s_kept, cnt);
+        if (i < npad) {
+            if (by_rank) ek[i] = en.key;
+            else e[i] = en;
+        }
     }
-    sort_entries(e, npad, tid, 1024);
+    __syncthreads();
+    RAG_STAMP(4);
     const int m = s_kept < p.limit ? s_kept : p.limit;
-    const double hi = m > 0 ? c_sc[e[0].idx] : 0.0, lo = m > 0 ? c_sc[e[m - 1].idx] : 0.0;
+    if (by_rank) {
+        // (score, position) pairs are distinct, so "entries that sort before mine" is a rank; every lane reads
+        // the same key at a time (an LDS broadcast) and no barrier separates the steps -- the 45 barrier steps
+        // of a 512-entry bitonic sort took a third of this kernel's time
+        // work is dealt so that all 16 waves take part: `parts` threads share a candidate, each counts over its
+        // slice of the keys (keys above mine, and keys not below: equal scores are rare and settled afterwards)
+        int* rank_gt = reinterpret_cast<int*>(ek + npad);      // [npad] behind the keys, inside the entry array
+        int* rank_ge = rank_gt + npad;                         // [npad]
+        for (int i = tid; i < 2 * npad; i += 1024) rank_gt[i] = 0;
+        __syncthreads();
+        const int lg = 31 - __clz(npad);                       // npad is a power of two <= 1024
+        const int parts = 1024 >> lg;
+        {
+            const int i = tid & (npad - 1), part = tid >> lg;
+            const u64 mine = i < pool ? ek[i] : 0;
+            if (mine != 0) {
+                const int j_lo = (pool * part) >> (10 - lg), j_hi = (pool * (part + 1)) >> (10 - lg);
+                int gt = 0, ge = 0;
+#pragma unroll 8
+                for (int j = j_lo; j < j_hi; ++j) {
+                    const u64 kj = ek[j];
+                    gt += kj > mine ? 1 : 0;
+                    ge += kj >= mine ? 1 : 0;
+                }
+                if (parts > 1) { atomicAdd(&rank_gt[i], gt); atomicAdd(&rank_ge[i], ge); }
+                else { rank_gt[i] = gt; rank_ge[i] = ge; }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < pool; i += 1024) {
+            const u64 mine = ek[i];
+            if (mine == 0) continue;
+            int before = rank_gt[i];
+            if (rank_ge[i] - before > 1)                       // equal scores: the earlier candidate first
+                for (int j = 0; j < i; ++j) before += ek[j] == mine ? 1 : 0;
+            if (before < m) order[before] = i;
+        }
+        __syncthreads();
+    } else {
+        sort_entries(e, npad, tid, 1024);
+        for (int r = tid; r < m; r += 1024) order[r] = (int)e[r].idx;
+        __syncthreads();
+    }
+    RAG_STAMP(5);
+    const double hi = m > 0 ? c_sc[order[0]] : 0.0, lo = m > 0 ? c_sc[order[m - 1]] : 0.0;
     for (int r = tid; r < m; r += 1024) {
-        const int i = (int)e[r].idx;
+        const int i = order[r];
         const double sc = c_sc[i];
         p.f_rows[r] = c_row[i];
         p.f_score[r] = sc;
@@ -623,13 +735,15 @@ __global__ __launch_bounds__(1024) void hybrid_fuse_kernel(HybridArgs p) {
         p.rel[r] = hi > lo ? (sc - lo) / (hi - lo) : 1.0;
     }
     if (tid == 0) { *p.n_fused = m; *p.status = zero_div ? 1 : 0; }
+    RAG_STAMP(6);
 }
 
 static size_t hybrid_fuse_lds(int topn, int nb) {
     const size_t NC = (size_t)topn + nb;
     size_t npad = 2;
     while (npad < NC) npad <<= 1;
-    return npad * sizeof(SortEntry) + NC * (3 * sizeof(double) + sizeof(long long)) + (size_t)nb * (4 * sizeof(int) + sizeof(long long)) + NC + 64 + 16;
+    return npad * sizeof(SortEntry) + NC * (3 * sizeof(double) + sizeof(long long)) + (size_t)nb * (4 * sizeof(int) + sizeof(long long)) + NC +
+           NC * sizeof(int) + 4 + 64 + 16;
 }
 
 static thread_local Workspace g_fuse_ws[64];

@@ -65,3 +65,18 @@ hipError_t launch_ingest_rows(const float* src, long long n, int d, int ld, int 
 hipError_t launch_gather_rows(const float* X, int d, int ld, long long n, const long long* rows, long long ntotal, float* out, hipStream_t s);
 
 }  // namespace rag
+
+// Diagnostic builds (-DRAG_STAMPS): thread 0 of a single-workgroup kernel records the 100 MHz wall clock at
+// numbered points in a per-source-file array; RAG_STAMPS_DEFINE(tag) in that file defines the array and
+// rag_debug_stamps_<tag>() (not part of the ABI), which copies it out.  Compiled away otherwise.
+#ifdef RAG_STAMPS
+#define RAG_STAMPS_DEFINE(tag)                                                                        \
+    static __device__ long long g_rag_stamps[64];                                                     \
+    extern "C" int rag_debug_stamps_##tag(long long* out) {                                           \
+        return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rag_stamps), sizeof(long long) * 64);        \
+    }
+#define RAG_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_rag_stamps[(i)] = (long long)wall_clock64(); } while (0)
+#else
+#define RAG_STAMPS_DEFINE(tag)
+#define RAG_STAMP(i) do { } while (0)
+#endif
