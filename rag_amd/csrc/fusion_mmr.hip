@@ -73,10 +73,12 @@ __global__ __launch_bounds__(256) void fuse_kernel(FuseArgs p) {
                 en.key = f64_ordered(sc);
                 if (en.key == 0) en.key = 1;
                 en.idx = (uint32_t)i;
-                atomicAdd(&s_kept, 1);
             }
         }
         e[i] = en;
+        // npad is a power of two: a wave's lanes are in this trip together or (npad < 64) lane 0 is among them
+        const int cnt = __popcll(__ballot(en.key != 0));
+        if ((tid & 63) == 0 && cnt > 0) atomicAdd(&s_kept, cnt);
     }
     sort_entries(e, p.npad, tid, 256);
     const int kept = s_kept;
@@ -129,6 +131,38 @@ __global__ __launch_bounds__(64) void mmr_prepare_kernel(MmrArgs p, MmrState st)
         if (p.pos) xr = p.pos[xr];
     }
     double ss = 0.0;
+    constexpr int PJ = 16;
+    if (d <= 64 * PJ) {
+        // the row fits the wave's registers (16 values per lane): read once, written once, already divided --
+        // no trip through memory between the norm and the division.  Same sum order as the loop below.
+        double v[PJ];
+#pragma unroll
+        for (int t = 0; t < PJ; ++t) {
+            const int j = lane + 64 * t;
+            v[t] = 0.0;
+            if (j < d) {
+                if (p.X) v[t] = (double)p.X[xr * (long long)p.ld + j];
+                else if (p.emb_is_f64) v[t] = static_cast<const double*>(p.emb)[(size_t)c * d + j];
+                else v[t] = (double)static_cast<const float*>(p.emb)[(size_t)c * d + j];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < PJ; ++t)
+            if (lane + 64 * t < d) ss = fma(v[t], v[t], ss);
+        double nrm = 1.0;
+        if (p.metric == RAG_MMR_COSINE) {
+            ss = wave_sum_f64(ss);
+            nrm = sqrt(ss);
+            if (nrm == 0.0) nrm = 1.0;
+        }
+#pragma unroll
+        for (int t = 0; t < PJ; ++t) {
+            const int j = lane + 64 * t;
+            if (j < d) p.En[(size_t)c * d + j] = p.metric == RAG_MMR_COSINE ? v[t] / nrm : v[t];
+        }
+        if (lane == 0 && st.maxsim) { st.maxsim[c] = -INFINITY; st.alive[c] = 1; }
+        return;
+    }
     for (int j = lane; j < d; j += 64) {
         double v;
         if (p.X) v = (double)p.X[xr * (long long)p.ld + j];
