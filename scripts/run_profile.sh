@@ -5,9 +5,10 @@ set -o pipefail
 export TMPDIR=/tmp
 OUT=gpurun_out/prof
 mkdir -p $OUT
-timeout -k 10 400 python3 bench.py --steps 50 > $OUT/bench.json 2> $OUT/bench.err
+timeout -k 10 400 python3 bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 tail -c 600 $OUT/bench.json; echo
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 20 --warmup 3 --no-cpu --no-prefilter --big-steps 3 > $OUT/bench_traced.json 2> $OUT/trace.err
+# the same command under the kernel trace
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 20 --warmup 5 > $OUT/bench_traced.json 2> $OUT/trace.err
 f=$(ls $OUT/trace/*/*kernel_stats.csv | head -1)
 (head -1 $f; grep "rag::" $f) > $OUT/kernel_stats_rag.csv
 cat $OUT/kernel_stats_rag.csv
