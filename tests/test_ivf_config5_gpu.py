@@ -40,7 +40,8 @@ def test_config5_shape_against_the_oracle():
     idx.add(X[100_000:])
     detail = ivf.ivf_assign_detail(X, C)
     total_excused = 0
-    for lo, hi, path in ((0, 64, "ivf"), (64, 364, "ivf-listmajor"), (0, 1, "ivf")):
+    # 1, 2 and 4 queries take the dedicated coarse step (scores of all lists, then one selection workgroup per query)
+    for lo, hi, path in ((0, 64, "ivf"), (64, 364, "ivf-listmajor"), (0, 1, "ivf"), (5, 7, "ivf"), (7, 10, "ivf"), (10, 14, "ivf")):
         D, I = idx.search(Q[lo:hi], K, nprobe=NPROBE)
         assert idx.last_path == path
         bad, excused, amb = ivf.ivf_check(D, I, X, C, Q[lo:hi], K, NPROBE, detail=detail, rtol=RTOL, atol=ATOL)
@@ -48,7 +49,7 @@ def test_config5_shape_against_the_oracle():
         total_excused += excused
         assert bad == [], bad[:5]
     # the comparison is not vacuous: nearly every query must agree with the oracle outright
-    assert total_excused <= 10
+    assert total_excused <= 12
     # a masked search (payload filter) at the same shape
     mask = (rng.uniform(size=n) < 0.5).astype(np.uint8)
     D, I = idx.search(Q[:64], K, nprobe=NPROBE, row_mask=mask, min_score=0.3)

@@ -218,3 +218,28 @@ def test_ivf_snapshot_round_trip(tmp_path):
     open(bad, "wb").write(bytes(raw[: len(raw) // 2]))
     with pytest.raises(RagHipError):
         DeviceIndex.load(bad)
+
+
+def test_coarse_selection_with_thousands_of_equal_list_scores():
+    """The coarse step of 1, 2 and 4 queries selects the nprobe best of all list scores with a histogram
+    bound that narrows while too many keys share a bucket: 2900 identical centroids give 2900 exactly
+    equal scores, and the cut falls in their middle (lower list first, as everywhere)."""
+    from rag_amd import DeviceIndex
+    rng = np.random.default_rng(404)
+    n, d, nlist, k = 30_000, 64, 4096, 10
+    C = _unit(rng, nlist, d)
+    C[100:3000] = C[100]
+    X = _unit(rng, n, d)
+    X[:4000] = (C[100] + 0.05 * rng.standard_normal((4000, d))).astype(np.float32)      # rows that land in the equal lists
+    idx = DeviceIndex(d, metric="ip", kind="ivf")
+    idx.train_ivf(nlist, centroids=C)
+    idx.add(X)
+    Q = _unit(rng, 8, d)
+    Q[0] = C[100]
+    Q[1] = -C[100]
+    for nprobe in (1, 37, 600, 1024):
+        for lo, hi in ((0, 1), (1, 3), (3, 7), (0, 3)):          # 3 queries take the general path
+            D, I = idx.search(Q[lo:hi], k, nprobe=nprobe)
+            assert idx.last_path in ("ivf", "ivf-listmajor")       # 4 queries x 1024 probes reach one pair per list
+            _check_ivf(D, I, X, C, Q[lo:hi], k, nprobe)
+    idx.close()
