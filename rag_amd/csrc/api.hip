@@ -161,7 +161,7 @@ static int append_ids(rag_index* h, long long count, const int64_t* ids) {
 
 int ivf_assign_new_rows(rag_index* h, long long first, long long count);   // ivf.hip
 int ivf_search_device(rag_index* h, long long nq, const float* qbuf, int k, float min_score, int nprobe,
-                      const uint8_t* mask, float* D, long long* I, hipStream_t s);
+                      const uint8_t* mask, const uint8_t* mask2, float* D, long long* I, hipStream_t s);
 void ivf_free(rag_index* h);
 size_t ivf_search_workspace(const rag_index* h, long long nq, int k, int nprobe);
 int gemm_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask,
@@ -573,7 +573,9 @@ static int search_device_ordered(rag_index* h, int64_t nq, const float* q_dev, i
     }
     // effective row mask = soft-delete mask AND caller's filter mask
     const uint8_t* mask = row_mask_dev;
-    if (h->active) {
+    if (h->active && h->kind == RAG_KIND_IVF) {
+        // the IVF kernels take both masks and read them where a row is tested
+    } else if (h->active) {
         if (row_mask_dev) {
             if (int rc = h->ws2.ensure((size_t)h->n)) return rc;
             hipLaunchKernelGGL(and_masks_kernel, dim3(grid_for(h->n)), dim3(256), 0, s, h->active, row_mask_dev, h->n,
@@ -597,7 +599,7 @@ static int search_device_ordered(rag_index* h, int64_t nq, const float* q_dev, i
     else
         RAG_HIP_CHECK(launch_prep_queries(q_dev, nq, h->dim, h->ld, 0 + (h->metric == RAG_METRIC_COSINE), static_cast<float*>(h->ws.ptr), s));
     if (h->kind == RAG_KIND_IVF)
-        return ivf_search_device(h, nq, qbuf, k, min_score, nprobe, mask, D_dev, I, s);
+        return ivf_search_device(h, nq, qbuf, k, min_score, nprobe, h->active, row_mask_dev, D_dev, I, s);
     return flat_search_prepared(h, nq, qbuf, k, min_score, mask, D_dev, I, s);
 }
 

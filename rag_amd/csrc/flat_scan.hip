@@ -178,7 +178,10 @@ __global__ __launch_bounds__(256) void flat_scan_kernel(ScanArgs a) {
         if (lane < TILE) {
             const long long r = row0 + lane;
             rv = r < r_end;
-            if (rv && a.mask) rv = a.mask[r] != 0;
+            if (rv && (a.mask || a.mask2)) {
+                const long long mr = a.mask_aliased ? a.row_alias[r] : r;
+                rv = (!a.mask || a.mask[mr] != 0) && (!a.mask2 || a.mask2[mr] != 0);
+            }
         }
         const u64 rowvalid = __ballot(rv);
 

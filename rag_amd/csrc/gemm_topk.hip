@@ -103,6 +103,8 @@ struct GemmArgs {
     const float* X;
     const float* Q;
     const uint8_t* mask;
+    const uint8_t* mask2;  // a second mask (soft deletes and the caller's filter, not AND-ed first)
+    int mask_aliased;      // 1: the masks count rows as row_alias does (insertion order), not storage order
     u64* cand;       // [grid][QT][TRIG + RT]
     u64* part;       // [nq][S][outc]
     const float* margin;   // bf16 pass: per query, how far below the k-th approximate score a row is kept
@@ -168,9 +170,12 @@ template <int RT, int QT>
 __device__ RAG_PUSH_ATTR void push_candidate(const GemmArgs& a, u64* cand, int* s_cnt, int* s_flag, int ql,
                                              long long row, long long row_hi, float sc) {
     constexpr int CAPQ = gemm_capq(RT, QT);
-    if (row < row_hi && (!a.mask || a.mask[row])) {
+    if (row >= row_hi) return;
+    const long long shown = a.row_alias ? a.row_alias[row] : row;       // the row number keys (and aliased masks) use
+    const long long mr = a.mask_aliased ? shown : row;
+    if ((!a.mask || a.mask[mr]) && (!a.mask2 || a.mask2[mr])) {
         const int pos = atomicAdd(&s_cnt[ql], 1);
-        cand[(size_t)ql * CAPQ + pos] = make_key(sc, (uint32_t)(a.row_alias ? a.row_alias[row] : row));
+        cand[(size_t)ql * CAPQ + pos] = make_key(sc, (uint32_t)shown);
         if (pos + 1 > a.trig) *s_flag = 1;       // compact before the next tile can overflow it
     }
 }
@@ -1072,7 +1077,7 @@ size_t ivf_listmajor_workspace(const rag_index* h, long long nq, int k, int npro
 }
 
 int ivf_listmajor_scan(rag_index* h, long long nq, const float* qbuf, int k, float min_score, int nprobe,
-                       const long long* coarse_lists, const uint8_t* packed_mask, float* D, long long* I, hipStream_t s) {
+                       const long long* coarse_lists, const uint8_t* mask, const uint8_t* mask2, float* D, long long* I, hipStream_t s) {
     const IvfState& v = h->ivf;
     const size_t nlist = (size_t)v.nlist, npairs = (size_t)nq * nprobe;
     const size_t qbytes = ((size_t)nq * h->ld * sizeof(float) + 255) & ~(size_t)255;
@@ -1099,7 +1104,9 @@ int ivf_listmajor_scan(rag_index* h, long long nq, const float* qbuf, int k, flo
     GemmArgs a = {};
     a.X = h->X;
     a.Q = qbuf;
-    a.mask = packed_mask;
+    a.mask = mask;                 // both masks count rows in insertion order, like the keys
+    a.mask2 = mask2;
+    a.mask_aliased = 1;
     a.cand = cand;
     a.part = part;
     a.n = h->n;

@@ -44,11 +44,6 @@ __global__ void gather_packed_rows_kernel(const float* src, const long long* src
     }
 }
 
-__global__ void gather_mask_kernel(const uint8_t* mask, const long long* orig, long long n, uint8_t* out) {
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-        out[i] = mask[orig[i]];
-}
-
 // ---------------------------------------------------------------------------------------------
 // Coarse step of a few queries (nq <= 4): the centroid table is small (nlist x ld fp32, 64 MB at
 // 16384 x 1024: it stays in the Infinity Cache between queries), so the table is scored without any
@@ -293,7 +288,7 @@ static long long ivf_slices(const rag_index* h, long long nq, int nprobe) {
 bool ivf_listmajor_supported(const rag_index* h, long long nq, int k, int nprobe);            // gemm_topk.hip
 size_t ivf_listmajor_workspace(const rag_index* h, long long nq, int k, int nprobe);
 int ivf_listmajor_scan(rag_index* h, long long nq, const float* qbuf, int k, float min_score, int nprobe,
-                       const long long* coarse_lists, const uint8_t* packed_mask, float* D, long long* I, hipStream_t s);
+                       const long long* coarse_lists, const uint8_t* mask, const uint8_t* mask2, float* D, long long* I, hipStream_t s);
 
 // bytes the list scan needs in h->ws after the padded queries
 size_t ivf_search_workspace(const rag_index* h, long long nq, int k, int nprobe) {
@@ -413,7 +408,7 @@ int ivf_reconstruct_rows(rag_index* h, long long n, const int64_t* rows, std::ve
 }
 
 int ivf_search_device(rag_index* h, long long nq, const float* qbuf, int k, float min_score, int nprobe,
-                      const uint8_t* mask, float* D, long long* I, hipStream_t s) {
+                      const uint8_t* mask, const uint8_t* mask2, float* D, long long* I, hipStream_t s) {
     IvfState& v = h->ivf;
     if (!v.quantizer) return fail(RAG_ERR_INVALID, "IVF index is not trained");
     if (nprobe < 1) return fail(RAG_ERR_INVALID, "nprobe must be >= 1");
@@ -427,28 +422,21 @@ int ivf_search_device(rag_index* h, long long nq, const float* qbuf, int k, floa
     // --- coarse: the nprobe best lists of every query --------------------------------------
     const size_t cdb = ((size_t)nq * nprobe * sizeof(float) + 255) & ~(size_t)255;
     const size_t cib = ((size_t)nq * nprobe * sizeof(long long) + 255) & ~(size_t)255;
-    const size_t mb = mask ? (((size_t)n + 255) & ~(size_t)255) : 0;
+    const size_t mb = 0;          // masks are read through row_alias where a row is tested: no packed copy
     const bool direct = nq != 3 && coarse_direct_ok(v.quantizer, nq, nprobe);
     const size_t sb = direct ? (((size_t)nq * v.nlist * sizeof(float) + 255) & ~(size_t)255) : 0;
     if (int rc = v.ws.ensure(cdb + cib + mb + sb)) return rc;
     float* cD = static_cast<float*>(v.ws.ptr);
     long long* cI = reinterpret_cast<long long*>(static_cast<char*>(v.ws.ptr) + cdb);
-    uint8_t* pmask = mask ? reinterpret_cast<uint8_t*>(static_cast<char*>(v.ws.ptr) + cdb + cib) : nullptr;
     if (direct) {
         float* scores = reinterpret_cast<float*>(static_cast<char*>(v.ws.ptr) + cdb + cib + mb);
         if (int rc = coarse_direct(v.quantizer, nq, qbuf, nprobe, scores, cD, cI, s)) return rc;
     } else if (int rc = flat_search_prepared(v.quantizer, nq, qbuf, nprobe, -FLT_MAX, nullptr, cD, cI, s)) {
         return rc;
     }
-    if (mask) {
-        long long mblocks = (n + 255) / 256;
-        if (mblocks > 4096) mblocks = 4096;
-        hipLaunchKernelGGL(gather_mask_kernel, dim3((unsigned)mblocks), dim3(256), 0, s, mask, v.orig_dev, n, pmask);
-        RAG_HIP_CHECK(hipGetLastError());
-    }
     // --- list scan ------------------------------------------------------------------------------
     if (ivf_listmajor_supported(h, nq, k, nprobe)) {
-        if (int rc = ivf_listmajor_scan(h, nq, qbuf, k, min_score, nprobe, cI, pmask, D, I, s)) return rc;
+        if (int rc = ivf_listmajor_scan(h, nq, qbuf, k, min_score, nprobe, cI, mask, mask2, D, I, s)) return rc;
         h->last_path = "ivf-listmajor";
         return RAG_OK;
     }
@@ -464,7 +452,9 @@ int ivf_search_device(rag_index* h, long long nq, const float* qbuf, int k, floa
         ScanArgs a = {};
         a.X = h->X;
         a.Q = qbuf + (size_t)q0 * h->ld;
-        a.mask = pmask;
+        a.mask = mask;
+        a.mask2 = mask2;
+        a.mask_aliased = 1;
         a.part = part;
         a.n = n;
         a.d4 = h->ld / 4;

@@ -12,6 +12,8 @@ struct ScanArgs {
     const float* X;        // corpus rows, row stride ld = 4*d4 floats, 16-byte aligned
     const float* Q;        // nq padded queries, stride ld
     const uint8_t* mask;   // nullptr or n bytes, 1 = row may be returned
+    const uint8_t* mask2;  // a second mask of the same kind (soft deletes and the caller's filter need not be AND-ed first)
+    int mask_aliased;      // 1: the masks count rows as row_alias does (insertion order), not storage order
     u64* part;             // [nq][waves][k] per-wave candidate keys
     long long n;           // rows
     int d4;                // float4 per row

@@ -243,3 +243,37 @@ def test_coarse_selection_with_thousands_of_equal_list_scores():
             assert idx.last_path in ("ivf", "ivf-listmajor")       # 4 queries x 1024 probes reach one pair per list
             _check_ivf(D, I, X, C, Q[lo:hi], k, nprobe)
     idx.close()
+
+
+def test_ivf_soft_deletes_and_filter_mask_together():
+    """Soft-deleted rows and a caller's filter mask on an IVF index: both byte arrays count rows in insertion
+    order and are read through the storage -> insertion map where a row is tested (no packed copy, no AND pass);
+    per-query scan, list-major scan and the coarse step of few queries."""
+    from rag_amd import DeviceIndex
+    rng = np.random.default_rng(606)
+    n, d, nlist, nprobe, k = 40_000, 128, 1024, 24, 10
+    X = _unit(rng, n, d)
+    C = X[rng.choice(n, nlist, replace=False)].copy()
+    idx = DeviceIndex(d, metric="ip", kind="ivf")
+    idx.train_ivf(nlist, centroids=C)
+    idx.add(X[:30_000])
+    idx.search(X[:1], 1, nprobe=nprobe)                        # packs the first rows
+    idx.add(X[30_000:])
+    dead = rng.choice(n, 6000, replace=False)
+    idx.set_active(dead, False)
+    alive = np.ones(n, np.uint8)
+    alive[dead] = 0
+    flt = (rng.uniform(size=n) < 0.5).astype(np.uint8)
+    for nq in (1, 2, 3, 40, 300):
+        Q = X[rng.choice(n, nq)] + 0.05 * rng.standard_normal((nq, d)).astype(np.float32)
+        for mask, both in ((None, alive), (flt, alive & flt)):
+            D, I = idx.search(Q, k, nprobe=nprobe, row_mask=mask)
+            _check_ivf(D, I, X, C, Q, k, nprobe, row_mask=both)
+            got = I[I >= 0]
+            assert both[got].all()
+    # restoring the rows brings them back
+    idx.set_active(dead, True)
+    Q = X[dead[:5]]
+    D, I = idx.search(Q, 1, nprobe=nprobe)
+    assert np.array_equal(I[:, 0], dead[:5])
+    idx.close()
