@@ -51,6 +51,11 @@ int rag_version(void);
 /* thread-local message of the last failing call on this thread */
 const char* rag_last_error(void);
 int rag_device_count(int* count);
+/* Host-pointer searches, rag_merge_topk_device and the fusion / MMR entry points stage their data in
+ * device memory that belongs to the calling host thread (grow-only, one block per purpose and device).
+ * A thread that is about to end -- a worker of a thread pool that is being resized -- hands it back
+ * with this call; it must not race with another call of the same thread (it cannot) and is optional. */
+int rag_thread_release(void);
 
 /* ---- index lifetime ------------------------------------------------------
  * One rag_index_t replaces one Qdrant collection + its QdrantSearchOptimizer

@@ -34,6 +34,7 @@ SIGNATURES = {
     "rag_version": (_i32, []),
     "rag_last_error": (C.c_char_p, []),
     "rag_device_count": (_i32, [C.POINTER(_i32)]),
+    "rag_thread_release": (_i32, []),
     "rag_index_create": (_i32, [_i32, _i32, _i32, _i32, C.POINTER(_vp)]),
     "rag_index_free": (_i32, [_vp]),
     "rag_index_reserve": (_i32, [_vp, _i64]),

@@ -37,6 +37,9 @@ void Workspace::release() {
     bytes = 0;
 }
 
+static thread_local Workspace g_thread_ws[TWS_KINDS][64];
+Workspace& thread_workspace(int which, int device) { return g_thread_ws[which][device & 63]; }
+
 struct DeviceGuard {
     int prev = -1;
     bool ok = true;
@@ -306,6 +309,20 @@ extern "C" {
 
 int rag_version(void) { return RAG_ABI_VERSION; }
 const char* rag_last_error(void) { return g_err.c_str(); }
+
+int rag_thread_release(void) {
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    for (int dev = 0; dev < 64; ++dev) {
+        bool any = false;
+        for (int w = 0; w < TWS_KINDS; ++w) any = any || g_thread_ws[w][dev].ptr != nullptr;
+        if (!any) continue;
+        if (hipSetDevice(dev) != hipSuccess) continue;
+        for (int w = 0; w < TWS_KINDS; ++w) g_thread_ws[w][dev].release();
+    }
+    if (prev >= 0) (void)hipSetDevice(prev);
+    return RAG_OK;
+}
 
 int rag_device_count(int* count) {
     if (!count) return fail(RAG_ERR_INVALID, "count is NULL");
@@ -625,8 +642,7 @@ int rag_index_search(rag_index_t* h, int64_t nq, const float* q, int k, float mi
     RAG_LOCK_INDEX(h);
     DeviceGuard g(h->device);
     // staging in a separate allocation from the search workspaces
-    static thread_local Workspace stage[64];
-    Workspace& st = stage[h->device & 63];
+    Workspace& st = thread_workspace(TWS_STAGE, h->device);
     const size_t qb = ((size_t)nq * h->dim * sizeof(float) + 255) & ~(size_t)255;
     const size_t db = ((size_t)nq * k * sizeof(float) + 255) & ~(size_t)255;
     const size_t ib = ((size_t)nq * k * sizeof(long long) + 255) & ~(size_t)255;
@@ -786,8 +802,7 @@ int rag_merge_topk_device(int nlists, int64_t nq, int k, const float* D_dev, int
     if (nq == 0) return RAG_OK;
     DeviceGuard g(device);
     if (!g.ok) return fail(RAG_ERR_HIP, "hipSetDevice failed");
-    static thread_local Workspace keyws[64];
-    Workspace& ws = keyws[device & 63];
+    Workspace& ws = thread_workspace(TWS_MERGE, device);
     if (int rc = ws.ensure((size_t)nq * nlists * k * sizeof(u64))) return rc;
     return merge_topk_with_keys(nlists, nq, k, D_dev, d_list_stride, I_dev, i_list_stride, D_out_dev, I_out_dev,
                                 static_cast<u64*>(ws.ptr), static_cast<hipStream_t>(stream));

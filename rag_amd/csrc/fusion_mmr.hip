@@ -780,7 +780,6 @@ static size_t hybrid_fuse_lds(int topn, int nb) {
            NC * sizeof(int) + 4 + 64 + 16;
 }
 
-static thread_local Workspace g_fuse_ws[64];
 
 static int current_device(int* dev) {
     RAG_HIP_CHECK(hipGetDevice(dev));
@@ -802,7 +801,7 @@ static int run_fuse(int mode, int64_t n, const double* a, const double* b, const
     }
     int dev = 0;
     if (int rc = current_device(&dev)) return rc;
-    Workspace& ws = g_fuse_ws[dev & 63];
+    Workspace& ws = thread_workspace(TWS_FUSE, dev);
     const size_t nb = (size_t)n * sizeof(double);
     const size_t nbp = (nb + 255) & ~(size_t)255;
     const size_t fb = ((size_t)n + 255) & ~(size_t)255;
@@ -915,7 +914,7 @@ static int run_mmr(int device, int64_t n, int d, const void* emb, int emb_is_f64
     RAG_HIP_CHECK(hipGetDevice(&prev));
     if (prev != device) RAG_HIP_CHECK(hipSetDevice(device));
     struct Restore { int p, d; ~Restore() { if (p != d) (void)hipSetDevice(p); } } restore{prev, device};
-    Workspace& ws = g_fuse_ws[device & 63];
+    Workspace& ws = thread_workspace(TWS_FUSE, device);
     const bool sim = n <= mmr_sim_limit();
     const size_t esz = emb_is_f64 ? 8 : 4;
     const size_t eb = X ? al256((size_t)n * 8) : al256((size_t)n * d * esz);

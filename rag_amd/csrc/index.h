@@ -33,6 +33,11 @@ struct Workspace {
     void release();
 };
 
+// Staging memory of the calling host thread, per purpose and device (host-pointer searches, the
+// multi-GPU merge, fusion / MMR): grow-only like every workspace, handed back by rag_thread_release().
+enum { TWS_STAGE = 0, TWS_MERGE = 1, TWS_FUSE = 2, TWS_KINDS = 3 };
+Workspace& thread_workspace(int which, int device);
+
 // RAII-free helpers: record an event pair around a launch when profiling is on
 int profile_begin(rag_index* h, hipStream_t s);
 int profile_end(rag_index* h, hipStream_t s);

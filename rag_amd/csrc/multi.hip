@@ -57,7 +57,10 @@ class Worker {
             {
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_.wait(lk, [this] { return stop_ || (busy_ && job_); });
-                if (stop_) return;
+                if (stop_) {
+                    (void)rag_thread_release();        // this thread's staging memory on its device
+                    return;
+                }
                 job = std::move(job_);
                 job_ = nullptr;
             }

@@ -84,3 +84,34 @@ def test_multi_device_errors_name_the_device():
     assert "device 0" in str(e.value)
     assert len(m) == 0
     m.close()
+
+
+def test_thread_staging_memory_can_be_handed_back():
+    """rag_thread_release frees the calling thread's staging blocks; the next call allocates them again."""
+    import threading
+    import torch
+    from rag_amd import DeviceIndex, _lib
+    rng = np.random.default_rng(9)
+    d = 512
+    X = _unit(rng, 8000, d)                                # 8000 queries x 512 floats: a 16 MB staging block
+    idx = DeviceIndex(d, metric="ip")
+    idx.add(X)
+    D0, I0 = idx.search(X, 5)
+    out = []
+
+    def worker():
+        free0, _ = torch.cuda.mem_get_info(0)
+        out.append(idx.search(X, 5))                       # this thread's staging block appears ...
+        free1, _ = torch.cuda.mem_get_info(0)
+        assert _lib.lib.rag_thread_release() == 0          # ... and goes away
+        free2, _ = torch.cuda.mem_get_info(0)
+        out.append((free0, free1, free2))
+        out.append(idx.search(X, 5))                       # and the thread can go on searching
+
+    t = threading.Thread(target=worker)
+    t.start()
+    t.join()
+    (D1, I1), (free0, free1, free2), (D2, I2) = out
+    assert np.array_equal(I0, I1) and np.array_equal(I0, I2) and np.array_equal(D0, D2)
+    assert free0 - free1 >= 8 << 20 and free2 - free1 >= 8 << 20
+    idx.close()
