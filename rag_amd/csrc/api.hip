@@ -177,6 +177,10 @@ int prefilter_scan_search(rag_index* h, const float* qbuf, int k, float min_scor
 size_t gemm_topk_workspace(const rag_index* h, long long nq, int k);
 bool narrow_topk_supported(const rag_index* h, long long nq, int k);          // narrow_topk.hip
 size_t narrow_topk_workspace(const rag_index* h, long long nq, int k);
+bool direct_topk_supported(const rag_index* h, long long nq, int k);                      // direct_topk.hip
+size_t direct_topk_workspace(const rag_index* h, long long nq);
+int direct_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask,
+                       float* D, long long* I, float* scores, hipStream_t s);
 int narrow_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask,
                        float* D, long long* I, hipStream_t s);
 int ivf_reconstruct_rows(rag_index* h, long long n, const int64_t* rows, std::vector<long long>& storage_rows);
@@ -280,8 +284,11 @@ static int flat_scan_search(rag_index* h, long long nq, const float* qbuf, int k
 // bytes the exhaustive search needs in h->ws after the padded queries
 // 5..32 queries without the bf16 first pass: the register-streaming kernel (one corpus pass at the HBM rate)
 static bool use_narrow(const rag_index* h, long long nq, int k) { return !h->prefilter && narrow_topk_supported(h, nq, k); }
+// 1, 2 or 4 queries over a corpus of at most 2^20 rows: every row scored, one selection workgroup per query
+static bool use_direct(const rag_index* h, long long nq, int k) { return !h->prefilter && direct_topk_supported(h, nq, k); }
 
 size_t flat_search_workspace(const rag_index* h, long long nq, int k) {
+    if (use_direct(h, nq, k)) return direct_topk_workspace(h, nq);
     if (use_narrow(h, nq, k)) return narrow_topk_workspace(h, nq, k);
     if (gemm_topk_supported(h, nq, k)) return gemm_topk_workspace(h, nq, k);
     if (prefilter_scan_supported(h, nq, k)) return prefilter_scan_workspace(h, k);
@@ -295,6 +302,8 @@ int flat_search_prepared(rag_index* h, long long nq, const float* qbuf, int k, f
                          float* D, long long* I, hipStream_t s) {
     const size_t qbytes = ((size_t)nq * h->ld * sizeof(float) + 255) & ~(size_t)255;
     if (int rc = h->ws.ensure(qbytes + flat_search_workspace(h, nq, k))) return rc;
+    if (use_direct(h, nq, k))
+        return direct_topk_search(h, nq, qbuf, k, min_score, mask, D, I, reinterpret_cast<float*>(static_cast<char*>(h->ws.ptr) + qbytes), s);
     if (use_narrow(h, nq, k)) return narrow_topk_search(h, nq, qbuf, k, min_score, mask, D, I, s);
     if (gemm_topk_supported(h, nq, k)) return gemm_topk_search(h, nq, qbuf, k, min_score, mask, D, I, s);
     if (prefilter_scan_supported(h, nq, k)) return prefilter_scan_search(h, qbuf, k, min_score, mask, D, I, s);

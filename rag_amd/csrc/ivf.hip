@@ -44,232 +44,11 @@ __global__ void gather_packed_rows_kernel(const float* src, const long long* src
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Coarse step of a few queries (nq <= 4): the centroid table is small (nlist x ld fp32, 64 MB at
-// 16384 x 1024: it stays in the Infinity Cache between queries), so the table is scored without any
-// selection in the scan -- every wave would see a few dozen rows and hand all of them over anyway --
-// and one workgroup per query then selects the nprobe best of the nlist scores.
-//
-// coarse_scores_kernel: 16 lanes per centroid, 4 centroids per wave instruction (4 x 256 contiguous
-// bytes); the queries sit in LDS; per (centroid, query) an fma chain per lane, then a 4-step xor tree.
-typedef float f4c __attribute__((ext_vector_type(4)));
-template <int NQ>
-__global__ __launch_bounds__(256) void coarse_scores_kernel(const float* C, int nlist, int ld, const float* Q, float* scores) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    f4c* q4 = reinterpret_cast<f4c*>(smem);                  // [NQ][ld4]
-    const int ld4 = ld / 4;
-    for (int i = threadIdx.x; i < NQ * ld4; i += 256) q4[i] = reinterpret_cast<const f4c*>(Q)[i];
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int sub = lane >> 4, c = lane & 15;
-    const long long wave = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;
-    const long long nwaves = ((long long)gridDim.x * 256) >> 6;
-    const f4c* C4 = reinterpret_cast<const f4c*>(C);
-    for (long long r0 = wave * 4; r0 < nlist; r0 += nwaves * 4) {
-        const long long r = r0 + sub;
-        const long long rr = r < nlist ? r : nlist - 1;
-        float acc[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) acc[q] = 0.f;
-        // 16 loads (4 KB of the row group) go out together: one memory latency per 1024 floats of row width.
-        // Cached loads: the table is re-read by every query.
-        for (int i0 = c; i0 < ld4; i0 += 256) {
-            f4c x[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int i = i0 + 16 * u;
-                x[u] = i < ld4 ? C4[rr * ld4 + i] : (f4c){0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int i = i0 + 16 * u;
-                if (i < ld4) {
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) {
-                        const f4c w = q4[q * ld4 + i];
-                        acc[q] = fmaf(x[u].x, w.x, acc[q]);
-                        acc[q] = fmaf(x[u].y, w.y, acc[q]);
-                        acc[q] = fmaf(x[u].z, w.z, acc[q]);
-                        acc[q] = fmaf(x[u].w, w.w, acc[q]);
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) acc[q] += __shfl_xor(acc[q], off, 64);
-            if (c == 0 && r < nlist) scores[(size_t)q * nlist + r] = acc[q];
-        }
-    }
-}
-
-// coarse_select_kernel: the nprobe best (score descending, ties to the lower list) of nlist scores, one
-// workgroup per query.  Keys (ordered score | ~list) are distinct, so the selection is a search for a
-// bound with at least nprobe and at most SEL_CAP keys at or above it, followed by a rank count among the
-// survivors.  The bound comes from a 1024-bucket histogram over a key range that is narrowed to the bucket
-// of the nprobe-th key for as long as too many keys share it.  The first attempt bins only the 1024
-// per-thread maxima ("heads": the nprobe-th largest head has nprobe keys at or above it) -- one LDS atomic
-// per thread, spread over the upper tail, where binning all nlist keys piles most of them onto the few
-// buckets of the bulk; if the heads do not settle it (fewer than nprobe heads, or thousands of equal
-// scores behind the bound) every key is binned.
-constexpr int SEL_CAP = 4096;
-__global__ __launch_bounds__(1024) void coarse_select_kernel(const float* scores, int nlist, int nprobe, float* D, long long* I) {
-    __shared__ int hist[1024];
-    __shared__ u64 cand[SEL_CAP];
-    __shared__ u64 s_lo, s_hi, s_bound;
-    __shared__ int s_cnt, s_above, s_done;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const float* sc = scores + (size_t)blockIdx.x * nlist;
-    if (tid == 0) { s_lo = ~0ull; s_hi = 0ull; }
-    __syncthreads();
-    u64 head = KEY_EMPTY;                                          // this thread's best key
-    {
-        u64 mn = ~0ull, mx = 0ull;
-        for (int i0 = tid; i0 < nlist; i0 += 8 * 1024) {           // eight loads per memory latency
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = i0 + u * 1024 < nlist ? sc[i0 + u * 1024] : NAN;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const u64 key = make_key(v[u], (uint32_t)(i0 + u * 1024));
-                if (key != KEY_EMPTY) { mn = key < mn ? key : mn; mx = key > mx ? key : mx; }
-            }
-        }
-        head = mx;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const u64 omn = shfl_xor_u64(mn, off), omx = shfl_xor_u64(mx, off);
-            mn = omn < mn ? omn : mn;
-            mx = omx > mx ? omx : mx;
-        }
-        if (lane == 0 && mx != 0ull) { atomicMin(&s_lo, mn); atomicMax(&s_hi, mx); }
-    }
-    const int nheads = __syncthreads_count(head != KEY_EMPTY);
-    const u64 glo = s_lo, ghi = s_hi;
-    int cnum = 0;
-    for (int mode = (nheads >= nprobe ? 0 : 1); mode < 2 && ghi >= glo; ++mode) {
-        const bool by_heads = mode == 0;
-        __syncthreads();
-        if (tid == 0) { s_cnt = 0; s_above = 0; s_done = 0; s_bound = KEY_EMPTY; s_lo = glo; s_hi = ghi; }
-        __syncthreads();
-        u64 lo = glo, hi = ghi;
-        // every pass keeps: keys above `hi` are selected for sure (s_above of them), the nprobe-th key lies in [lo, hi]
-        for (int pass = 0; pass < 8; ++pass) {
-            const int shift = (hi > lo) ? max(0, 64 - __clzll((long long)(hi - lo)) - 10) : 0;
-            hist[tid] = 0;
-            __syncthreads();
-            if (by_heads) {
-                if (head != KEY_EMPTY && head >= lo && head <= hi) atomicAdd(&hist[(int)((head - lo) >> shift)], 1);
-            } else {
-                for (int i = tid; i < nlist; i += 1024) {
-                    const u64 key = make_key(sc[i], (uint32_t)i);
-                    if (key != KEY_EMPTY && key >= lo && key <= hi) atomicAdd(&hist[(int)((key - lo) >> shift)], 1);
-                }
-            }
-            __syncthreads();
-            if (tid < 64) {
-                const int need = nprobe - s_above;
-                int own = 0;
-#pragma unroll
-                for (int b = 0; b < 16; ++b) own += hist[tid * 16 + b];
-                int suf = own;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const int up = __shfl_down(suf, off, 64);
-                    if (tid + off < 64) suf += up;
-                }
-                const int higher = suf - own;
-                const int total = __shfl(suf, 0, 64);             // keys inside [lo, hi]
-                if (total < need) {
-                    if (tid == 0) { s_bound = lo; s_done = 1; }   // fewer keys than asked for: take them all
-                } else if (higher < need && suf >= need) {
-                    int cnt = higher, b = 15;
-                    for (; b >= 0; --b) {
-                        cnt += hist[tid * 16 + b];
-                        if (cnt >= need) break;
-                    }
-                    const u64 edge = lo + ((u64)(tid * 16 + b) << shift);
-                    // heads: any edge with nprobe heads at or above it is a bound (how many keys stand behind it shows
-                    // when they are collected); all keys: the survivors must fit the candidate array
-                    if (by_heads || s_above + cnt <= SEL_CAP || shift == 0) { s_bound = edge; s_done = 1; }
-                    else {
-                        // too many keys share the bucket of the nprobe-th: those above the bucket are in, look inside it
-                        s_above += cnt - hist[tid * 16 + b];
-                        s_lo = edge;
-                        s_hi = edge + ((1ull << shift) - 1ull);
-                    }
-                }
-            }
-            __syncthreads();
-            if (s_done) break;
-            lo = s_lo;
-            hi = s_hi;
-            __syncthreads();
-        }
-        const u64 bound = s_bound;
-        if (bound != KEY_EMPTY) {
-            for (int i0 = tid; i0 < nlist; i0 += 8 * 1024) {
-                float v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = i0 + u * 1024 < nlist ? sc[i0 + u * 1024] : NAN;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const u64 key = make_key(v[u], (uint32_t)(i0 + u * 1024));
-                    if (key != KEY_EMPTY && key >= bound) {
-                        const int pos = atomicAdd(&s_cnt, 1);
-                        if (pos < SEL_CAP) cand[pos] = key;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        cnum = s_cnt;
-        if (cnum <= SEL_CAP) break;                                // settled; otherwise bin every key
-        cnum = 0;
-    }
-    for (int j = tid; j < nprobe; j += 1024) {                     // slots that stay empty
-        D[(size_t)blockIdx.x * nprobe + j] = -FLT_MAX;
-        I[(size_t)blockIdx.x * nprobe + j] = -1;
-    }
-    __syncthreads();
-    for (int i = tid; i < cnum; i += 1024) {
-        const u64 mine = cand[i];
-        int above = 0;
-#pragma unroll 8
-        for (int j = 0; j < cnum; ++j) above += cand[j] > mine ? 1 : 0;
-        if (above < nprobe) {
-            D[(size_t)blockIdx.x * nprobe + above] = key_score(mine);
-            I[(size_t)blockIdx.x * nprobe + above] = (long long)key_row(mine);
-        }
-    }
-}
-
-// the dedicated coarse step: a few queries, a table that one select workgroup can walk
-static bool coarse_direct_ok(const rag_index* qz, long long nq, int nprobe) {
-    static const int on = getenv("RAG_IVF_COARSE_DIRECT") ? atoi(getenv("RAG_IVF_COARSE_DIRECT")) : 1;   // measurement knob
-    return on && nq >= 1 && nq <= 4 && qz->n >= 1024 && qz->n <= (1 << 20) && nprobe <= 1024 && (size_t)4 * qz->ld * 4 <= 48 * 1024 &&
-           !qz->active && !qz->ids_dev;
-}
-
-static int coarse_direct(rag_index* qz, long long nq, const float* qbuf, int nprobe, float* scores, float* cD, long long* cI, hipStream_t s) {
-    const int nlist = (int)qz->n;
-    const int nqk = nq == 1 ? 1 : nq == 2 ? 2 : 4;               // query slots of the kernel; surplus slots repeat the last query
-    long long groups = (nlist + 3) / 4;                          // 4 centroids per wave step
-    static const int max_waves = std::max(64, getenv("RAG_IVF_COARSE_WAVES") ? atoi(getenv("RAG_IVF_COARSE_WAVES")) : 4096);   // measurement knob
-    long long waves = std::min<long long>(groups, max_waves);
-    const int blocks = (int)std::max<long long>(1, (waves + 3) / 4);
-    const size_t lds = (size_t)nqk * qz->ld * sizeof(float);
-    // the padded query buffer holds nq rows; a kernel with more slots than queries must not read past it
-    if (nqk != nq) return fail(RAG_ERR_INVALID, "internal: coarse step called with 3 queries");
-    if (nqk == 1) hipLaunchKernelGGL(coarse_scores_kernel<1>, dim3(blocks), dim3(256), lds, s, qz->X, nlist, qz->ld, qbuf, scores);
-    else if (nqk == 2) hipLaunchKernelGGL(coarse_scores_kernel<2>, dim3(blocks), dim3(256), lds, s, qz->X, nlist, qz->ld, qbuf, scores);
-    else hipLaunchKernelGGL(coarse_scores_kernel<4>, dim3(blocks), dim3(256), lds, s, qz->X, nlist, qz->ld, qbuf, scores);
-    RAG_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(coarse_select_kernel, dim3((unsigned)nq), dim3(1024), 0, s, scores, nlist, nprobe, cD, cI);
-    RAG_HIP_CHECK(hipGetLastError());
-    return RAG_OK;
-}
+// the coarse step of a few queries: every list scored, then one selection workgroup per query (direct_topk.hip)
+bool direct_topk_supported(const rag_index* h, long long nq, int k);
+size_t direct_topk_workspace(const rag_index* h, long long nq);
+int direct_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask,
+                       float* D, long long* I, float* scores, hipStream_t s);
 
 constexpr long long IVF_QCHUNK = 32768;     // queries per launch (grid.y) and workspace bound
 
@@ -423,14 +202,14 @@ int ivf_search_device(rag_index* h, long long nq, const float* qbuf, int k, floa
     const size_t cdb = ((size_t)nq * nprobe * sizeof(float) + 255) & ~(size_t)255;
     const size_t cib = ((size_t)nq * nprobe * sizeof(long long) + 255) & ~(size_t)255;
     const size_t mb = 0;          // masks are read through row_alias where a row is tested: no packed copy
-    const bool direct = nq != 3 && coarse_direct_ok(v.quantizer, nq, nprobe);
-    const size_t sb = direct ? (((size_t)nq * v.nlist * sizeof(float) + 255) & ~(size_t)255) : 0;
+    const bool direct = direct_topk_supported(v.quantizer, nq, nprobe);
+    const size_t sb = direct ? direct_topk_workspace(v.quantizer, nq) : 0;
     if (int rc = v.ws.ensure(cdb + cib + mb + sb)) return rc;
     float* cD = static_cast<float*>(v.ws.ptr);
     long long* cI = reinterpret_cast<long long*>(static_cast<char*>(v.ws.ptr) + cdb);
     if (direct) {
         float* scores = reinterpret_cast<float*>(static_cast<char*>(v.ws.ptr) + cdb + cib + mb);
-        if (int rc = coarse_direct(v.quantizer, nq, qbuf, nprobe, scores, cD, cI, s)) return rc;
+        if (int rc = direct_topk_search(v.quantizer, nq, qbuf, nprobe, -FLT_MAX, nullptr, cD, cI, scores, s)) return rc;
     } else if (int rc = flat_search_prepared(v.quantizer, nq, qbuf, nprobe, -FLT_MAX, nullptr, cD, cI, s)) {
         return rc;
     }

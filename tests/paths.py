@@ -5,6 +5,8 @@ assert that a case exercises the kernel it is meant for."""
 
 def flat_fp32_path(n, d, nq, k):
     ld = (d + 3) // 4 * 4
+    if nq in (1, 2, 4) and 1024 <= n <= (1 << 20) and 1 <= k <= 1024 and ld <= 3072:
+        return "direct"
     if 5 <= nq <= 32 and k <= 32 and n >= 4096 and ld % 128 == 0:
         nj = 1 if nq <= 16 else 2
         if ld * nj * 64 + 8 * 4096 + 8 * nj * 16 * 8 + 48 <= 160 * 1024:

@@ -40,7 +40,8 @@ def test_flat_ip_matches_oracle(n, d):
         assert D.dtype == np.float32 and I.dtype == np.int64 and D.shape == (nq, 10)
         _check(D, I, X, Q[:nq], 10)
         if nq <= 4:
-            assert idx.last_path == "scan"
+            from paths import flat_fp32_path
+            assert idx.last_path == flat_fp32_path(n, d, nq, 10)
     idx.close()
 
 
