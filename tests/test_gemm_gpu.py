@@ -96,7 +96,7 @@ def test_batch_and_single_query_kernels_agree_bitwise_on_ids():
     Dg, Ig = idx.search(Q, 10)
     assert idx.last_path == "narrow"
     rows = [idx.search(Q[i], 10) for i in range(32)]
-    assert idx.last_path == "direct"                      # one query over 60,000 rows: scores of all rows, then a selection
+    assert idx.last_path == "scan"
     Is = np.concatenate([r[1] for r in rows])
     Ds = np.concatenate([r[0] for r in rows])
     assert np.array_equal(Ig, Is)
