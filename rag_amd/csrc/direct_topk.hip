@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void direct_scores_kernel(const float* C, int 
 // buckets of the bulk; if the heads do not settle it (fewer than k heads, or thousands of equal
 // scores behind the bound) every key is binned.
 constexpr int SEL_CAP = 4096;
-constexpr int SEL_REG = 32;            // scores per thread held in registers: n <= 32768
+constexpr int SEL_REG_MAX = 32;        // scores per thread held in registers: n <= 32768
 struct SelectArgs {
     const float* scores;         // [nq][n]
     int n, k;
@@ -97,6 +97,7 @@ struct SelectArgs {
     long long* rows_out;         // nullptr or [nq][k]: row position of every hit (-1 where I is -1)
 };
 
+template <int SEL_REG>                  // scores per thread: n <= SEL_REG * 1024
 __global__ __launch_bounds__(1024) void direct_select_kernel(SelectArgs p) {
     const int n = p.n, k = p.k;
     const float* scores = p.scores;
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(1024) void direct_select_kernel(SelectArgs p) {
 
 bool direct_topk_supported(const rag_index* h, long long nq, int k) {
     static const int on = getenv("RAG_DIRECT_TOPK") ? atoi(getenv("RAG_DIRECT_TOPK")) : 1;          // measurement knob
-    return on && h->kind == RAG_KIND_FLAT && (nq == 1 || nq == 2 || nq == 4) && h->n >= 1024 && h->n <= SEL_REG * 1024 &&
+    return on && h->kind == RAG_KIND_FLAT && (nq == 1 || nq == 2 || nq == 4) && h->n >= 1024 && h->n <= SEL_REG_MAX * 1024 &&
            k >= 1 && k <= 1024 && (size_t)4 * h->ld * 4 <= 48 * 1024;
 }
 
@@ -276,7 +277,9 @@ int direct_topk_search(rag_index* h, long long nq, const float* qbuf, int k, flo
     p.D = D;
     p.I = I;
     p.rows_out = h->merge_rows_out;
-    hipLaunchKernelGGL(direct_select_kernel, dim3((unsigned)nq), dim3(1024), 0, s, p);
+    if (n <= 8 * 1024) hipLaunchKernelGGL(direct_select_kernel<8>, dim3((unsigned)nq), dim3(1024), 0, s, p);
+    else if (n <= 16 * 1024) hipLaunchKernelGGL(direct_select_kernel<16>, dim3((unsigned)nq), dim3(1024), 0, s, p);
+    else hipLaunchKernelGGL(direct_select_kernel<SEL_REG_MAX>, dim3((unsigned)nq), dim3(1024), 0, s, p);
     RAG_HIP_CHECK(hipGetLastError());
     h->last_path = "direct";
     return RAG_OK;
