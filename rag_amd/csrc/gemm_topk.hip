@@ -203,7 +203,9 @@ __device__ __forceinline__ int count_above(const u64* sorted, int n, float thr, 
 // tighten the threshold
 template <int RT, int QT, int NW, bool B16>
 __device__ __forceinline__ void compact_queries(u64* scratch, u64* cand, int* s_cnt, float* s_thr, const float* s_margin,
-                                                int* overflow, unsigned int* gthr, int k, int TRIG, int wave, int lane) {
+                                                int* overflow, unsigned int* gthr, const int* qmap, int k, int TRIG, int wave, int lane) {
+    // gthr[qmap ? qmap[ql] : ql] is the query's shared threshold (work items of the list-major scan map their
+    // columns to queries through qmap)
     constexpr int CAPQ = gemm_capq(RT, QT);
     for (int ql = wave; ql < QT; ql += NW) {
         const int c = s_cnt[ql];
@@ -228,7 +230,7 @@ __device__ __forceinline__ void compact_queries(u64* scratch, u64* cand, int* s_
             s_cnt[ql] = keep;
             if (c >= k) {
                 s_thr[ql] = thr;
-                if (gthr) atomicMax(&gthr[ql], f32_ordered(thr));
+                if (gthr) atomicMax(&gthr[qmap ? qmap[ql] : ql], f32_ordered(thr));
             }
         }
         SyncWave()();
@@ -451,7 +453,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
                 // passed the barrier above, so the flag is stable and stage buf^1 is idle
                 if (kt == 0 && *s_flag != 0) {
                     compact_queries<RT, QT, NW, B16>(reinterpret_cast<u64*>(As + (buf ^ 1) * TILEA) + wave * CAPQ2, cand, s_cnt, s_thr, s_margin,
-                                                     a.overflow, (!TASKS && a.gthr) ? a.gthr + q0 : nullptr, k, a.trig, wave, lane);
+                                                     a.overflow, a.gthr ? (TASKS ? a.gthr : a.gthr + q0) : nullptr, TASKS ? a.pair_q + p0 : nullptr, k, a.trig,
+                                                     wave, lane);
                     __syncthreads();
                     if (tid == 0) *s_flag = 0;
                 }
@@ -466,15 +469,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
                 for (int nj = 0; nj < NJ; ++nj) fb[0][nj] = *reinterpret_cast<const f4*>(Bb + nj * 32 * GK + foff[0]);
                 if (!B16 || RAG_B16_SCHED) __builtin_amdgcn_sched_group_barrier(0x100, READS, 0);
             }
-            if constexpr (!TASKS) {
-                if (kt == KT - 1 && a.gthr) {
+            if (kt == KT - 1 && a.gthr) {
 #pragma unroll
-                    for (int nj = 0; nj < NJ; ++nj) {
-                        const int ql = wq * NJ * 32 + nj * 32 + l31;
-                        if (ql < m_valid) {
-                            const unsigned int o = __hip_atomic_load(&a.gthr[q0 + ql], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (o != 0u) tg[nj] = ordered_f32(o);
-                        }
+                for (int nj = 0; nj < NJ; ++nj) {
+                    const int ql = wq * NJ * 32 + nj * 32 + l31;
+                    if (ql < m_valid) {
+                        // a work item of the list-major scan finds its column's query through pair_q: every list a
+                        // query probes competes for the same k places, so the lists share the query's threshold
+                        const int qg = TASKS ? a.pair_q[p0 + ql] : q0 + ql;
+                        const unsigned int o = __hip_atomic_load(&a.gthr[qg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (o != 0u) tg[nj] = ordered_f32(o);
                     }
                 }
             }
@@ -1073,7 +1077,7 @@ bool ivf_listmajor_supported(const rag_index* h, long long nq, int k, int nprobe
 size_t ivf_listmajor_workspace(const rag_index* h, long long nq, int k, int nprobe) {
     const size_t nlist = (size_t)h->ivf.nlist, npairs = (size_t)nq * nprobe;
     return 4 * lm_align(nlist * 4) + 256 + lm_align((std::min(nlist, npairs) + npairs / 32 + 64) * 4) + 2 * lm_align(npairs * 4) +
-           (size_t)LM_GRID * 32 * gemm_capq(256, 32) * sizeof(u64) + lm_align(npairs * k * sizeof(u64));
+           (size_t)LM_GRID * 32 * gemm_capq(256, 32) * sizeof(u64) + lm_align(npairs * k * sizeof(u64)) + lm_align((size_t)nq * 4);
 }
 
 int ivf_listmajor_scan(rag_index* h, long long nq, const float* qbuf, int k, float min_score, int nprobe,
@@ -1093,7 +1097,10 @@ int ivf_listmajor_scan(rag_index* h, long long nq, const float* qbuf, int k, flo
     int* pair_q = reinterpret_cast<int*>(w);             w += lm_align(npairs * 4);
     int* pair_slot = reinterpret_cast<int*>(w);          w += lm_align(npairs * 4);
     u64* cand = reinterpret_cast<u64*>(w);               w += (size_t)LM_GRID * 32 * gemm_capq(256, 32) * sizeof(u64);
-    u64* part = reinterpret_cast<u64*>(w);
+    u64* part = reinterpret_cast<u64*>(w);               w += lm_align(npairs * k * sizeof(u64));
+    unsigned int* gthr = reinterpret_cast<unsigned int*>(w);
+    static const int share_thr = env_int_g("RAG_IVF_SHARE_THR", 1);                // measurement knob
+    RAG_HIP_CHECK(hipMemsetAsync(gthr, 0, (size_t)nq * 4, s));
     RAG_HIP_CHECK(hipMemsetAsync(cnt, 0, 2 * lm_align(nlist * 4), s));          // cnt and fill
     RAG_HIP_CHECK(hipMemsetAsync(part, 0, npairs * k * sizeof(u64), s));        // pairs without rows stay empty
     const int pb = (int)std::min<size_t>((npairs + 255) / 256, 4096);
@@ -1104,6 +1111,7 @@ int ivf_listmajor_scan(rag_index* h, long long nq, const float* qbuf, int k, flo
     GemmArgs a = {};
     a.X = h->X;
     a.Q = qbuf;
+    a.gthr = share_thr ? gthr : nullptr;
     a.mask = mask;                 // both masks count rows in insertion order, like the keys
     a.mask2 = mask2;
     a.mask_aliased = 1;
