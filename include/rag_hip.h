@@ -136,8 +136,26 @@ int rag_index_search_device(rag_index_t* h, int64_t nq, const float* q_dev, int 
 int rag_index_search_segments(rag_index_t* h, int64_t nq, const float* q, int64_t nseg,
                               const int64_t* seg_begin, const int64_t* seg_end, int k,
                               float min_score, const uint8_t* row_mask, float* D, int64_t* I);
+/* The segment search above followed on the device by the fusion of
+ * vector_db/search_manager.py:898-932: every hit's score (widened to fp64) times the
+ * weight of its query vector (:902); per segment and row the best weighted score, the
+ * earlier query vector winning equal scores (:904-909); all segments' entries sorted by
+ * that score, best first, equal scores in the order the reference's dictionaries would
+ * hold them (segment order, then the first list and rank at which the row shows up);
+ * the first `limit` returned (:928-932).  Segments stand for the reference's documents
+ * and must not share rows.
+ *   weights              nq fp64 (0.4 / 0.6 / 0.3 at :860-874)
+ *   k                    hits per (query vector, segment) pair (limit * 2 at :891); nq * k <= 1024
+ *   limit                1..1024
+ *   out_rows/out_scores/out_strategy   `limit` slots: row position, weighted score, index of
+ *                        the query vector that gave it; *n_out entries are filled */
+int rag_index_search_segments_fused(rag_index_t* h, int64_t nq, const float* q, const double* weights,
+                                    int64_t nseg, const int64_t* seg_begin, const int64_t* seg_end,
+                                    int k, float min_score, const uint8_t* row_mask, int limit,
+                                    int64_t* out_rows, double* out_scores, int32_t* out_strategy,
+                                    int32_t* n_out);
 /* which kernel path the last search on this index used ("scan", "gemm", "ivf", "ivf-listmajor",
- * "segments", "scan-bf16", "gemm-bf16") */
+ * "segments", "segments-fused", "direct", "scan-bf16", "gemm-bf16") */
 const char* rag_index_last_path(const rag_index_t* h);
 
 /* multi-GPU step after the all-gather of per-shard results: merge `nlists`

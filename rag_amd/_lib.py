@@ -54,6 +54,8 @@ SIGNATURES = {
     "rag_index_search": (_i32, [_vp, _i64, _vp, _i32, _f32, _i32, _vp, _vp, _vp]),
     "rag_index_search_device": (_i32, [_vp, _i64, _vp, _i32, _f32, _i32, _vp, _vp, _vp, _vp]),
     "rag_index_search_segments": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _f32, _vp, _vp, _vp]),
+    "rag_index_search_segments_fused": (_i32, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i32, _f32, _vp, _i32, _vp, _vp,
+                                               _vp, _vp]),
     "rag_index_last_path": (C.c_char_p, [_vp]),
     "rag_merge_topk_device": (_i32, [_i32, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _vp]),
     "rag_merge_topk_device_static": (_i32, [_i32, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _vp]),

@@ -177,6 +177,9 @@ int prefilter_scan_search(rag_index* h, const float* qbuf, int k, float min_scor
 size_t gemm_topk_workspace(const rag_index* h, long long nq, int k);
 bool narrow_topk_supported(const rag_index* h, long long nq, int k);          // narrow_topk.hip
 size_t narrow_topk_workspace(const rag_index* h, long long nq, int k);
+size_t fanout_workspace(long long nq, long long nseg, int k, int limit);                  // fanout.hip
+int fanout_fuse_enqueue(const float* D, const long long* R, const double* weights_host, int nq, long long nseg, int k, int limit,
+                        char* ws, long long** rows_out, double** scores_out, int** strat_out, int** n_out, hipStream_t s);
 bool direct_topk_supported(const rag_index* h, long long nq, int k);                      // direct_topk.hip
 size_t direct_topk_workspace(const rag_index* h, long long nq);
 int direct_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask,
@@ -671,34 +674,40 @@ int rag_index_search(rag_index_t* h, int64_t nq, const float* q, int k, float mi
     return RAG_OK;
 }
 
-int rag_index_search_segments(rag_index_t* h, int64_t nq, const float* q, int64_t nseg, const int64_t* seg_begin,
-                              const int64_t* seg_end, int k, float min_score, const uint8_t* row_mask, float* D,
-                              int64_t* I) {
+// device part of a segment search: the k best of every (query, segment) pair left in h->ws2 as
+// D_dev / I_dev [nq][nseg][k] (and the row positions in R_dev when asked for); nothing synchronised.
+// `tail` extra bytes are reserved behind them in ws2 for the caller (*tail_dev).
+static int segments_check(rag_index_t* h, int64_t nq, const float* q, int64_t nseg, const int64_t* seg_begin,
+                          const int64_t* seg_end, int k, long long* rows_total) {
     if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
     if (h->kind != RAG_KIND_FLAT) return fail(RAG_ERR_UNSUPPORTED, "segment search needs a FLAT index");
     if (nq < 0 || nseg < 0) return fail(RAG_ERR_INVALID, "nq / nseg < 0");
     if (k < 1 || k > 1024) return fail(RAG_ERR_INVALID, "k must be in [1, 1024]");
     if (nq == 0 || nseg == 0) return RAG_OK;
-    if (!q || !seg_begin || !seg_end || !D || !I) return fail(RAG_ERR_INVALID, "NULL buffer");
+    if (!q || !seg_begin || !seg_end) return fail(RAG_ERR_INVALID, "NULL buffer");
     if (nq > 65535) return fail(RAG_ERR_INVALID, "at most 65535 queries per segment search");
-    long long rows_total = 0;
+    *rows_total = 0;
     for (int64_t i = 0; i < nseg; ++i) {
         if (seg_begin[i] < 0 || seg_end[i] < seg_begin[i] || seg_end[i] > h->n)
             return fail(RAG_ERR_INVALID, "segment " + std::to_string(i) + " is not a row range of the index");
-        rows_total += seg_end[i] - seg_begin[i];
+        *rows_total += seg_end[i] - seg_begin[i];
     }
-    RAG_LOCK_INDEX(h);
-    DeviceGuard g(h->device);
-    hipStream_t s = h->stream;
-    if (int rc = ws_acquire(h, s)) return rc;
+    return RAG_OK;
+}
+
+static int segments_enqueue(rag_index_t* h, int64_t nq, const float* q, int64_t nseg, const int64_t* seg_begin,
+                            const int64_t* seg_end, long long rows_total, int k, float min_score, const uint8_t* row_mask,
+                            bool want_rows, size_t tail, float** D_out, long long** I_out, long long** R_out, char** tail_dev,
+                            hipStream_t s) {
     // effective mask
     const uint8_t* mask = nullptr;
     const size_t mb = (((size_t)h->n + 255) & ~(size_t)255);
     const size_t sb = ((size_t)nseg * sizeof(long long) + 255) & ~(size_t)255;
     const size_t db = ((size_t)nq * nseg * k * sizeof(float) + 255) & ~(size_t)255;
     const size_t ib = ((size_t)nq * nseg * k * sizeof(long long) + 255) & ~(size_t)255;
+    const size_t rb = want_rows ? ib : 0;
     const size_t qhb = ((size_t)nq * h->dim * sizeof(float) + 255) & ~(size_t)255;
-    if (int rc = h->ws2.ensure(2 * mb + 2 * sb + db + ib + qhb)) return rc;
+    if (int rc = h->ws2.ensure(2 * mb + 2 * sb + db + ib + rb + qhb + tail)) return rc;
     char* base = static_cast<char*>(h->ws2.ptr);
     uint8_t* m_user = reinterpret_cast<uint8_t*>(base);
     uint8_t* m_comb = reinterpret_cast<uint8_t*>(base + mb);
@@ -706,7 +715,9 @@ int rag_index_search_segments(rag_index_t* h, int64_t nq, const float* q, int64_
     long long* d_se = reinterpret_cast<long long*>(base + 2 * mb + sb);
     float* D_dev = reinterpret_cast<float*>(base + 2 * mb + 2 * sb);
     long long* I_dev = reinterpret_cast<long long*>(base + 2 * mb + 2 * sb + db);
-    float* q_dev = reinterpret_cast<float*>(base + 2 * mb + 2 * sb + db + ib);
+    long long* R_dev = want_rows ? reinterpret_cast<long long*>(base + 2 * mb + 2 * sb + db + ib) : nullptr;
+    float* q_dev = reinterpret_cast<float*>(base + 2 * mb + 2 * sb + db + ib + rb);
+    if (tail_dev) *tail_dev = base + 2 * mb + 2 * sb + db + ib + rb + qhb;
     if (row_mask) {
         RAG_HIP_CHECK(hipMemcpyAsync(m_user, row_mask, (size_t)h->n, hipMemcpyHostToDevice, s));
         mask = m_user;
@@ -762,15 +773,83 @@ int rag_index_search_segments(rag_index_t* h, int64_t nq, const float* q, int64_
     m.min_score = min_score;
     m.row_ids = h->ids_dev;
     m.id_base = h->id_base;
-    m.rows_out = h->merge_rows_out;
+    m.rows_out = want_rows ? R_dev : h->merge_rows_out;
     m.D = D_dev;
     m.I = I_dev;
     RAG_HIP_CHECK(launch_merge_keys(m, nq * nseg, s));
+    *D_out = D_dev;
+    *I_out = I_dev;
+    if (R_out) *R_out = R_dev;
+    return RAG_OK;
+}
+
+int rag_index_search_segments(rag_index_t* h, int64_t nq, const float* q, int64_t nseg, const int64_t* seg_begin,
+                              const int64_t* seg_end, int k, float min_score, const uint8_t* row_mask, float* D,
+                              int64_t* I) {
+    long long rows_total = 0;
+    if (int rc = segments_check(h, nq, q, nseg, seg_begin, seg_end, k, &rows_total)) return rc;
+    if (nq == 0 || nseg == 0) return RAG_OK;
+    if (!D || !I) return fail(RAG_ERR_INVALID, "NULL buffer");
+    RAG_LOCK_INDEX(h);
+    DeviceGuard g(h->device);
+    hipStream_t s = h->stream;
+    if (int rc = ws_acquire(h, s)) return rc;
+    float* D_dev = nullptr;
+    long long* I_dev = nullptr;
+    if (int rc = segments_enqueue(h, nq, q, nseg, seg_begin, seg_end, rows_total, k, min_score, row_mask, false, 0, &D_dev, &I_dev,
+                                  nullptr, nullptr, s))
+        return rc;
     RAG_HIP_CHECK(hipMemcpyAsync(D, D_dev, (size_t)nq * nseg * k * sizeof(float), hipMemcpyDeviceToHost, s));
     RAG_HIP_CHECK(hipMemcpyAsync(I, I_dev, (size_t)nq * nseg * k * sizeof(long long), hipMemcpyDeviceToHost, s));
     RAG_HIP_CHECK(hipStreamSynchronize(s));
     h->ws_pending = false;
     h->last_path = "segments";
+    return RAG_OK;
+}
+
+// vector_db/search_manager.py:877-932 on the device: see include/rag_hip.h
+int rag_index_search_segments_fused(rag_index_t* h, int64_t nq, const float* q, const double* weights, int64_t nseg,
+                                    const int64_t* seg_begin, const int64_t* seg_end, int k, float min_score,
+                                    const uint8_t* row_mask, int limit, int64_t* out_rows, double* out_scores,
+                                    int32_t* out_strategy, int32_t* n_out) {
+    long long rows_total = 0;
+    if (int rc = segments_check(h, nq, q, nseg, seg_begin, seg_end, k, &rows_total)) return rc;
+    if (!n_out) return fail(RAG_ERR_INVALID, "n_out is NULL");
+    *n_out = 0;
+    if (limit < 1 || limit > 1024) return fail(RAG_ERR_INVALID, "limit must be in [1, 1024]");
+    if (nq == 0 || nseg == 0) return RAG_OK;
+    if (!weights || !out_rows || !out_scores || !out_strategy) return fail(RAG_ERR_INVALID, "NULL buffer");
+    if (nq > 16 || (long long)nq * k > 1024) return fail(RAG_ERR_INVALID, "at most 16 query vectors and nq * k <= 1024");
+    const size_t tail = fanout_workspace(nq, nseg, k, limit);
+    if (tail == 0) return fail(RAG_ERR_UNSUPPORTED, "too many (document, candidate) pairs for the fused ranking");
+    RAG_LOCK_INDEX(h);
+    DeviceGuard g(h->device);
+    hipStream_t s = h->stream;
+    if (int rc = ws_acquire(h, s)) return rc;
+    float* D_dev = nullptr;
+    long long* I_dev = nullptr;
+    long long* R_dev = nullptr;
+    char* tail_dev = nullptr;
+    if (int rc = segments_enqueue(h, nq, q, nseg, seg_begin, seg_end, rows_total, k, min_score, row_mask, true, tail, &D_dev, &I_dev,
+                                  &R_dev, &tail_dev, s))
+        return rc;
+    long long* rows_dev = nullptr;
+    double* scores_dev = nullptr;
+    int* strat_dev = nullptr;
+    int* n_dev = nullptr;
+    if (int rc = fanout_fuse_enqueue(D_dev, R_dev, weights, (int)nq, nseg, k, limit, tail_dev, &rows_dev, &scores_dev, &strat_dev,
+                                     &n_dev, s))
+        return rc;
+    int32_t n = 0;
+    RAG_HIP_CHECK(hipMemcpyAsync(&n, n_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+    RAG_HIP_CHECK(hipMemcpyAsync(out_rows, rows_dev, (size_t)limit * sizeof(long long), hipMemcpyDeviceToHost, s));
+    RAG_HIP_CHECK(hipMemcpyAsync(out_scores, scores_dev, (size_t)limit * sizeof(double), hipMemcpyDeviceToHost, s));
+    RAG_HIP_CHECK(hipMemcpyAsync(out_strategy, strat_dev, (size_t)limit * sizeof(int), hipMemcpyDeviceToHost, s));
+    RAG_HIP_CHECK(hipStreamSynchronize(s));
+    h->ws_pending = false;
+    h->last_path = "segments-fused";
+    if (n < 0 || n > limit) return fail(RAG_ERR_HIP, "fan-out ranking returned a bad count");
+    *n_out = n;
     return RAG_OK;
 }
 

@@ -216,6 +216,41 @@ class DeviceIndex:
                                             _ptr(D), _ptr(I)))
         return D, I
 
+    def search_segments_fused(self, q, weights, segments, k: int, limit: int, min_score: Optional[float] = None,
+                              row_mask=None):
+        """``search_segments`` followed on the device by the weighted best-per-row fusion
+        and the ranking of vector_db/search_manager.py:898-932.  ``weights``: one fp64
+        per query vector.  Returns numpy (rows int64, scores float64, strategy int32),
+        at most ``limit`` long, best first."""
+        k, limit = int(k), int(limit)
+        if not 1 <= k <= MAX_K or not 1 <= limit <= MAX_K:
+            raise ValueError(f"k and limit must be in [1, {MAX_K}]")
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        if q.ndim != 2 or q.shape[1] != self.dim:
+            raise ValueError(f"expected float32 [nq, {self.dim}] array, got {q.shape}")
+        w = np.ascontiguousarray(weights, dtype=np.float64).reshape(-1)
+        if w.size != q.shape[0]:
+            raise ValueError("one weight per query vector")
+        seg = np.ascontiguousarray(segments, dtype=np.int64).reshape(-1, 2)
+        sb = np.ascontiguousarray(seg[:, 0])
+        se = np.ascontiguousarray(seg[:, 1])
+        rows = np.full(limit, -1, dtype=np.int64)
+        scores = np.zeros(limit, dtype=np.float64)
+        strategy = np.full(limit, -1, dtype=np.int32)
+        n = C.c_int32(0)
+        m = None
+        if row_mask is not None:
+            m = np.ascontiguousarray(row_mask, dtype=np.uint8).reshape(-1)
+            if m.size != len(self):
+                raise ValueError("row_mask must have one byte per row")
+        ms = -FLT_MAX if min_score is None else float(min_score)
+        check(lib.rag_index_search_segments_fused(self._h, q.shape[0], _ptr(q), _ptr(w), seg.shape[0], _ptr(sb), _ptr(se),
+                                                  k, ms, _ptr(m), limit, _ptr(rows), _ptr(scores), _ptr(strategy),
+                                                  C.byref(n)))
+        return rows[:n.value], scores[:n.value], strategy[:n.value]
+
     def search(self, q, k: int, min_score: Optional[float] = None, nprobe: int = 1,
                row_mask=None) -> Tuple[object, object]:
         """Returns (D [nq,k] float32, I [nq,k] int64), numpy for numpy queries and
