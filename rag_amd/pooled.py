@@ -38,6 +38,7 @@ class PooledCollections:
         self._hidden: set = set()                           # soft-deleted collections
         self._version = 0                                   # bumped by every change of rows or payloads
         self._mask_cache: Dict[Tuple[str, str], Tuple[int, np.ndarray]] = {}
+        self._distinct_cache: Dict[str, Tuple[int, bool]] = {}
 
     def close(self) -> None:
         self.index.close()
@@ -172,6 +173,7 @@ class PooledCollections:
         self._hidden = set(meta["hidden"])
         self._version = 0
         self._mask_cache = {}
+        self._distinct_cache = {}
         return self
 
     def get_vector(self, name: str, point_id) -> Optional[np.ndarray]:
@@ -234,6 +236,48 @@ class PooledCollections:
                     hits.sort(key=lambda t: (-t[1], t[0]))
                     del hits[limit:]
         return out
+
+    def chunk_ids_distinct(self, name: str) -> bool:
+        """True when no two live points of the collection show the same chunk id in their
+        result dictionaries (kept until the pool changes)."""
+        hit = self._distinct_cache.get(name)
+        if hit is None or hit[0] != self._version:
+            rows = self._rows.get(name, {})
+            seen = {(self.payloads[r] or {}).get("chunk_id") or str(self.point_ids[r]) for r in rows.values()}
+            if len(self._distinct_cache) >= 65536:
+                self._distinct_cache.clear()
+            self._distinct_cache[name] = hit = (self._version, len(seen) == len(rows))
+        return hit[1]
+
+    def fused_search(self, names: Sequence[str], query_vectors, weights: Sequence[float], per_limit: int, limit: int,
+                     min_score: Optional[float] = 0.0, row_mask=None) -> Optional[List[Tuple[int, int, float, int]]]:
+        """The loop of vector_db/search_manager.py:879-932 over the collections ``names``
+        (documents, in order) and the query vectors (strategies, in order) as one device
+        call: [(index into names, row, weighted score, index of the winning query
+        vector)], best first, at most ``limit``.  None when the device call does not
+        apply (a collection spread over several row ranges, too many candidates per
+        collection); the caller then fuses the lists of ``search_many``."""
+        q = np.ascontiguousarray(query_vectors, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        if q.shape[0] > 16 or q.shape[0] * per_limit > 1024 or not 1 <= limit <= 1024 or per_limit < 1:
+            return None
+        segs, owner = [], []
+        for ci, name in enumerate(names):
+            live = [(b, e) for b, e in self.ranges.get(name, []) if e > b]
+            if len(live) > 1:
+                return None
+            if live:
+                segs.append(live[0])
+                owner.append(ci)
+        if not segs:
+            return []
+        rows, scores, strategy = self.index.search_segments_fused(q, weights, segs, per_limit, limit, min_score=min_score,
+                                                                  row_mask=row_mask)
+        begins = np.asarray([b for b, _e in segs], dtype=np.int64)
+        order = np.argsort(begins, kind="stable")
+        at = order[np.searchsorted(begins[order], rows, side="right") - 1] if len(rows) else []
+        return [(owner[int(si)], int(r), float(s), int(st)) for si, r, s, st in zip(at, rows, scores, strategy)]
 
     def chunks_of(self, hits: Sequence[Tuple[int, float]]) -> List[Tuple[Chunk, float]]:
         """(row, score) pairs as the reference's (Chunk, score) tuples

@@ -37,6 +37,24 @@ class HipSearchEngine:
         try:
             per_doc, hits_by_key = [], {}
             doc_ids = list(filters.document_ids or [])
+            # one device call for searches, weighting, best-per-chunk and ranking when the result keys
+            # "{document}_{chunk}" cannot collide across documents
+            keys_safe = len(set(doc_ids)) == len(doc_ids) and (len(doc_ids) < 2 or not any("_" in str(d) for d in doc_ids))
+            fused = getattr(self.storage_manager, "search_vectors_fused", None)
+            if keys_safe and fused is not None and query_embeddings:
+                ranked = await fused(
+                    [f"doc_{doc_id}" for doc_id in doc_ids], [vector for _name, vector, _weight in query_embeddings],
+                    [float(weight) for _name, _vector, weight in query_embeddings], vector_type="content",
+                    per_limit=limit * 2, limit=limit, score_threshold=filters.min_score or 0.1,
+                    metadata_filters={"user_id": filters.user_id} if filters.user_id else None)
+                if ranked is not None:
+                    out = []
+                    for _ni, hit, si in ranked:
+                        res = _result_from_hit(hit)
+                        if res is not None:
+                            res.metadata["search_strategy"] = query_embeddings[si][0]
+                            out.append(res)
+                    return out
             # the documents x strategies fan-out as one call (one device pass on a pooled manager)
             all_hits = await self.storage_manager.search_vectors_many(
                 [f"doc_{doc_id}" for doc_id in doc_ids], [vector for _name, vector, _weight in query_embeddings],

@@ -189,6 +189,52 @@ class VectorStorageManager:
             logger.error(f"Failed to search vectors in {len(index_names)} indexes: {e}")
             return out
 
+    async def search_vectors_fused(self, index_names: List[str], query_vectors: List[List[float]], weights: List[float],
+                                   vector_type: str = "content", per_limit: int = 20, limit: int = 10,
+                                   score_threshold: float = None, metadata_filters: Dict[str, Any] = None
+                                   ) -> Optional[List[Tuple[int, Dict[str, Any], int]]]:
+        """vector_db/search_manager.py:879-932 in one device call when every index sits in
+        the same pool: the searches of ``search_vectors_many``, each hit's score times the
+        weight of its query vector, the best per chunk, all documents ranked together.
+        Returns [(position in index_names, result dictionary with the weighted score,
+        position of the winning query vector)] best first, at most ``limit``; None when
+        the device call does not apply (indexes outside a pool or in several pools,
+        chunk ids repeated inside a collection, more candidates than the kernel takes)."""
+        try:
+            if not index_names or not len(query_vectors) or limit < 1 or per_limit < 1:
+                return None
+            pool, names, where = None, [], []
+            for ni, index_name in enumerate(index_names):
+                optimizer = self.search_optimizers.get(f"{index_name}_{vector_type}")
+                if not optimizer:
+                    logger.error(f"Failed to search vectors in index {index_name}: "
+                                 f"Search optimizer '{index_name}_{vector_type}' not found")
+                    continue
+                if not isinstance(optimizer, PooledView) or (pool is not None and optimizer.pool is not pool):
+                    return None
+                pool = optimizer.pool
+                if getattr(optimizer, "_disabled", False):
+                    continue
+                if not pool.chunk_ids_distinct(optimizer.collection_name):
+                    return None
+                names.append(optimizer.collection_name)
+                where.append(ni)
+            if pool is None or len(set(names)) != len(names):
+                return None
+            if not names:
+                return []
+            ranked = pool.fused_search(names, query_vectors, weights, device_limit(per_limit), limit,
+                                       min_score=score_threshold or 0.0, row_mask=pool.filter_mask(names, metadata_filters))
+            if ranked is None:
+                return None
+            out = []
+            for (ci, row, score, si), hit in zip(ranked, pool.hit_dicts([(row, score) for _ci, row, score, _si in ranked])):
+                out.append((where[ci], hit, si))
+            return out
+        except Exception as e:
+            logger.error(f"Fused search over {len(index_names)} indexes failed: {e}")
+            return None
+
     async def get_vector_by_chunk_id(self, chunk_id: str) -> Optional[Dict[str, Any]]:
         """storage_manager.py:558-602: first collection (content before context, in
         registration order) that holds the chunk.  A dictionary lookup per

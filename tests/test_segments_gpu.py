@@ -145,6 +145,20 @@ def test_pooled_manager_answers_like_the_per_collection_manager():
     assert [(r.document_id, r.chunk_id, r.metadata["search_strategy"]) for r in a] == \
            [(r.document_id, r.chunk_id, r.metadata["search_strategy"]) for r in b]
     assert np.allclose([r.score for r in a], [r.score for r in b], rtol=1e-6)
+    # documents with one row range each: searches, weighting and ranking are one device call, and the
+    # answer is that of the list-by-list fusion exactly (documents 4 and 9 above took the latter)
+    pool_index = pooled.search_optimizers["doc_1_content"].pool.index
+    for ids, lim, ms in (([d_ for d_ in docs if d_ not in (4, 9)] + [999], 10, None), ([3, 1, 2], 25, 0.05), ([5], 7, None)):
+        f1 = SearchFilters(user_id=7, document_ids=ids, min_score=ms)
+        fast = run(HipSearchEngine(pooled).semantic_search(strat, f1, lim))
+        assert pool_index.last_path == "segments-fused" and len(fast) > 0
+        pooled.search_vectors_fused = None
+        slow = run(HipSearchEngine(pooled).semantic_search(strat, f1, lim))
+        del pooled.search_vectors_fused
+        assert pool_index.last_path == "segments"
+        assert [(r.document_id, r.chunk_id, r.score, r.metadata) for r in fast] == \
+               [(r.document_id, r.chunk_id, r.score, r.metadata) for r in slow]
+        assert [r.text for r in fast] == [r.text for r in slow]
     a, b = (run(HipSearchEngine(m).contextual_semantic(Q[0].tolist(), filt, 5)) for m in (pooled, plain))
     assert [(r.document_id, r.chunk_id) for r in a] == [(r.document_id, r.chunk_id) for r in b] and len(a) > 50
     # vector fetch, soft delete / restore, delete
