@@ -87,6 +87,23 @@ for _ in range(20):
     pool.index.search_segments(Q, segs, 2 * limit, min_score=0.1)
 res["pooled_device_call_ms"] = (time.perf_counter() - t0) / 20 * 1e3
 
+# the same with weighting, best-per-chunk and ranking on the device (D2H of `limit` entries)
+w = [0.4, 0.6, 0.3]
+pool.index.search_segments_fused(Q, w, segs, 2 * limit, limit, min_score=0.1)
+t0 = time.perf_counter()
+for _ in range(20):
+    pool.index.search_segments_fused(Q, w, segs, 2 * limit, limit, min_score=0.1)
+res["pooled_fused_device_call_ms"] = (time.perf_counter() - t0) / 20 * 1e3
+# the engine method on the pooled manager without the fused call
+pmgr.search_vectors_fused = None
+eng = HipSearchEngine(pmgr)
+run(eng.semantic_search(strat, filt, limit))
+t0 = time.perf_counter()
+for _ in range(5):
+    run(eng.semantic_search(strat, filt, limit))
+res["engine_semantic_search_pooled_list_fusion_ms"] = (time.perf_counter() - t0) / 5 * 1e3
+del pmgr.search_vectors_fused
+
 # fusion + MMR on 200 candidates of a 1M x 768 corpus
 n, dd = 1_000_000, 768
 X = unit(n, dd)
