@@ -786,11 +786,12 @@ static int segments_enqueue(rag_index_t* h, int64_t nq, const float* q, int64_t 
 int rag_index_search_segments(rag_index_t* h, int64_t nq, const float* q, int64_t nseg, const int64_t* seg_begin,
                               const int64_t* seg_end, int k, float min_score, const uint8_t* row_mask, float* D,
                               int64_t* I) {
+    if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
+    RAG_LOCK_INDEX(h);
     long long rows_total = 0;
     if (int rc = segments_check(h, nq, q, nseg, seg_begin, seg_end, k, &rows_total)) return rc;
     if (nq == 0 || nseg == 0) return RAG_OK;
     if (!D || !I) return fail(RAG_ERR_INVALID, "NULL buffer");
-    RAG_LOCK_INDEX(h);
     DeviceGuard g(h->device);
     hipStream_t s = h->stream;
     if (int rc = ws_acquire(h, s)) return rc;
@@ -812,6 +813,8 @@ int rag_index_search_segments_fused(rag_index_t* h, int64_t nq, const float* q, 
                                     const int64_t* seg_begin, const int64_t* seg_end, int k, float min_score,
                                     const uint8_t* row_mask, int limit, int64_t* out_rows, double* out_scores,
                                     int32_t* out_strategy, int32_t* n_out) {
+    if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
+    RAG_LOCK_INDEX(h);
     long long rows_total = 0;
     if (int rc = segments_check(h, nq, q, nseg, seg_begin, seg_end, k, &rows_total)) return rc;
     if (!n_out) return fail(RAG_ERR_INVALID, "n_out is NULL");
@@ -822,7 +825,6 @@ int rag_index_search_segments_fused(rag_index_t* h, int64_t nq, const float* q, 
     if (nq > 16 || (long long)nq * k > 1024) return fail(RAG_ERR_INVALID, "at most 16 query vectors and nq * k <= 1024");
     const size_t tail = fanout_workspace(nq, nseg, k, limit);
     if (tail == 0) return fail(RAG_ERR_UNSUPPORTED, "too many (document, candidate) pairs for the fused ranking");
-    RAG_LOCK_INDEX(h);
     DeviceGuard g(h->device);
     hipStream_t s = h->stream;
     if (int rc = ws_acquire(h, s)) return rc;
