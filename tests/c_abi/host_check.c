@@ -122,6 +122,43 @@ int main(void) {
             brute(X, n, d, Q + (size_t)qi * d, (int)sb[s], (int)se[s], NULL, -FLT_MAX, k, Dr, Ir);
             CHECK(same_hits(Ds + (qi * 3 + s) * k, Is + (qi * 3 + s) * k, Dr, Ir, k), "segment (%d, %d) differs", qi, s);
         }
+    /* the same lists weighted, reduced to the best per row and ranked over all segments on the device:
+     * against a host fold of the lists above in the reference's loop order (segment, query, rank) */
+    {
+        const double wq[2] = {0.4, 0.6};
+        const int limit = 12;
+        int64_t fr[12];
+        double fs[12];
+        int32_t fq[12], fn = -1;
+        CHECK(rag_index_search_segments_fused(h, 2, Q, wq, 3, sb, se, k, -FLT_MAX, NULL, limit, fr, fs, fq, &fn) == RAG_OK,
+              "fused segments");
+        long long er[60];
+        double es[60];
+        int eq[60], ne = 0;
+        for (int s = 0; s < 3; ++s)
+            for (int qi = 0; qi < 2; ++qi)
+                for (int j = 0; j < k; ++j) {
+                    const int64_t r = Is[(qi * 3 + s) * k + j];
+                    if (r < 0) continue;
+                    const double w = (double)Ds[(qi * 3 + s) * k + j] * wq[qi];
+                    int at = -1;
+                    for (int e = 0; e < ne; ++e)
+                        if (er[e] == r) at = e;
+                    if (at < 0) { er[ne] = r; es[ne] = w; eq[ne] = qi; ++ne; }
+                    else if (w > es[at]) { es[at] = w; eq[at] = qi; }
+                }
+        CHECK(fn == (ne < limit ? ne : limit), "fused count %d", (int)fn);
+        unsigned char used[60] = {0};
+        for (int t = 0; t < fn; ++t) {            /* stable selection: best score, earliest entry on ties */
+            int best_e = -1;
+            for (int e = 0; e < ne; ++e)
+                if (!used[e] && (best_e < 0 || es[e] > es[best_e])) best_e = e;
+            used[best_e] = 1;
+            CHECK(fr[t] == er[best_e] && fs[t] == es[best_e] && fq[t] == eq[best_e], "fused entry %d differs", t);
+        }
+        CHECK(rag_index_search_segments_fused(h, 2, Q, wq, 3, sb, se, 600, -FLT_MAX, NULL, limit, fr, fs, fq, &fn) == RAG_ERR_INVALID,
+              "nq * k above 1024 accepted");
+    }
     se[2] = 20001;
     CHECK(rag_index_search_segments(h, 2, Q, 3, sb, se, k, -FLT_MAX, NULL, Ds, Is) == RAG_ERR_INVALID, "bad range accepted");
 
