@@ -102,23 +102,25 @@ int ivf_assign_new_rows(rag_index* h, long long first, long long count) {
         }
         return RAG_OK;
     }
+    // the rows go through the centroid search 65536 at a time (its workspace is sized per launch); every
+    // chunk's answers stay on the device and come back in one copy behind the last launch
     const long long chunk = 65536;
-    std::vector<long long> host_i((size_t)std::min(chunk, count));
+    const size_t db = ((size_t)std::min(chunk, count) * sizeof(float) + 255) & ~(size_t)255;
+    if (int rc = v.ws.ensure(db + (size_t)count * sizeof(long long))) return rc;
+    float* D = static_cast<float*>(v.ws.ptr);
+    long long* I = reinterpret_cast<long long*>(static_cast<char*>(v.ws.ptr) + db);
     for (long long c0 = 0; c0 < count; c0 += chunk) {
         const long long c = std::min(chunk, count - c0);
-        const size_t db = ((size_t)c * sizeof(float) + 255) & ~(size_t)255;
-        if (int rc = v.ws.ensure(db + (size_t)c * sizeof(long long))) return rc;
-        float* D = static_cast<float*>(v.ws.ptr);
-        long long* I = reinterpret_cast<long long*>(static_cast<char*>(v.ws.ptr) + db);
         // new rows sit at the tail of X in arrival order, already padded to ld
         const float* rows = h->X + (size_t)(first + c0) * h->ld;
-        if (int rc = flat_search_prepared(v.quantizer, c, rows, 1, -FLT_MAX, nullptr, D, I, h->stream)) return rc;
-        RAG_HIP_CHECK(hipMemcpyAsync(host_i.data(), I, (size_t)c * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
-        RAG_HIP_CHECK(hipStreamSynchronize(h->stream));
-        for (long long i = 0; i < c; ++i) {
-            const long long l = host_i[(size_t)i];
-            v.assign[(size_t)(first + c0 + i)] = l < 0 ? 0 : (int)l;     // a NaN row scores nowhere: list 0
-        }
+        if (int rc = flat_search_prepared(v.quantizer, c, rows, 1, -FLT_MAX, nullptr, D, I + c0, h->stream)) return rc;
+    }
+    std::vector<long long> host_i((size_t)count);
+    RAG_HIP_CHECK(hipMemcpyAsync(host_i.data(), I, (size_t)count * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+    RAG_HIP_CHECK(hipStreamSynchronize(h->stream));
+    for (long long i = 0; i < count; ++i) {
+        const long long l = host_i[(size_t)i];
+        v.assign[(size_t)(first + i)] = l < 0 ? 0 : (int)l;     // a NaN row scores nowhere: list 0
     }
     return RAG_OK;
 }
