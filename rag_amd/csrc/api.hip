@@ -287,7 +287,7 @@ static int flat_scan_search(rag_index* h, long long nq, const float* qbuf, int k
 // bytes the exhaustive search needs in h->ws after the padded queries
 // 5..32 queries without the bf16 first pass: the register-streaming kernel (one corpus pass at the HBM rate)
 static bool use_narrow(const rag_index* h, long long nq, int k) { return !h->prefilter && narrow_topk_supported(h, nq, k); }
-// 1, 2 or 4 queries over a corpus of at most 2^20 rows: every row scored, one selection workgroup per query
+// 1 to 4 queries over a corpus of at most 32768 rows: every row scored, one selection workgroup per query
 static bool use_direct(const rag_index* h, long long nq, int k) { return !h->prefilter && direct_topk_supported(h, nq, k); }
 
 size_t flat_search_workspace(const rag_index* h, long long nq, int k) {

@@ -1,5 +1,5 @@
 // Few queries over a corpus that one selection workgroup can hold in its registers (1024 .. 32768 rows;
-// 1, 2 or 4 queries, k <= 1024): every row is scored without any selection in the scan, then one
+// 1 to 4 queries, k <= 1024): every row is scored without any selection in the scan, then one
 // workgroup per query selects the k best of the n scores.  A scan whose waves see a few dozen rows each
 // hands all of them to the merge anyway; this is two short launches instead.  Used for the coarse step
 // of an IVF search (16384 centroids x 1024: 31.5 -> 23 us) and for small collections.  Above 32768 rows
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(1024) void direct_select_kernel(SelectArgs p) {
 
 bool direct_topk_supported(const rag_index* h, long long nq, int k) {
     static const int on = getenv("RAG_DIRECT_TOPK") ? atoi(getenv("RAG_DIRECT_TOPK")) : 1;          // measurement knob
-    return on && h->kind == RAG_KIND_FLAT && (nq == 1 || nq == 2 || nq == 4) && h->n >= 1024 && h->n <= SEL_REG_MAX * 1024 &&
+    return on && h->kind == RAG_KIND_FLAT && nq >= 1 && nq <= 4 && h->n >= 1024 && h->n <= SEL_REG_MAX * 1024 &&
            k >= 1 && k <= 1024 && (size_t)4 * h->ld * 4 <= 48 * 1024;
 }
 
@@ -263,6 +263,7 @@ int direct_topk_search(rag_index* h, long long nq, const float* qbuf, int k, flo
     if (int rc = profile_begin(h, s)) return rc;
     if (nq == 1) hipLaunchKernelGGL(direct_scores_kernel<1>, dim3(blocks), dim3(256), lds, s, h->X, n, h->ld, qbuf, scores);
     else if (nq == 2) hipLaunchKernelGGL(direct_scores_kernel<2>, dim3(blocks), dim3(256), lds, s, h->X, n, h->ld, qbuf, scores);
+    else if (nq == 3) hipLaunchKernelGGL(direct_scores_kernel<3>, dim3(blocks), dim3(256), lds, s, h->X, n, h->ld, qbuf, scores);
     else hipLaunchKernelGGL(direct_scores_kernel<4>, dim3(blocks), dim3(256), lds, s, h->X, n, h->ld, qbuf, scores);
     RAG_HIP_CHECK(hipGetLastError());
     if (int rc = profile_end(h, s)) return rc;

@@ -5,7 +5,7 @@ assert that a case exercises the kernel it is meant for."""
 
 def flat_fp32_path(n, d, nq, k):
     ld = (d + 3) // 4 * 4
-    if nq in (1, 2, 4) and 1024 <= n <= 32768 and 1 <= k <= 1024 and ld <= 3072:
+    if 1 <= nq <= 4 and 1024 <= n <= 32768 and 1 <= k <= 1024 and ld <= 3072:
         return "direct"
     if 5 <= nq <= 32 and k <= 32 and n >= 4096 and ld % 128 == 0:
         nj = 1 if nq <= 16 else 2

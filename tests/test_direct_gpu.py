@@ -31,7 +31,7 @@ def test_direct_path_matches_oracle(n, d):
     idx = DeviceIndex(d, metric="ip")
     idx.add(X[: n // 3])
     idx.add(X[n // 3:])
-    for nq in (1, 2, 4):
+    for nq in (1, 2, 3, 4):
         for k in (1, 10, 64, 200, 1024):
             D, I = idx.search(Q[:nq], k)
             assert idx.last_path == flat_fp32_path(n, d, nq, k) == "direct"
@@ -41,9 +41,9 @@ def test_direct_path_matches_oracle(n, d):
     assert idx.last_path == "direct"
     _check(D, I, X, Q, 10, row_mask=mask, min_score=0.02)
     assert mask[I[I >= 0]].all()
-    D, I = idx.search(Q[:3], 10)                              # three queries: the general path
+    D, I = idx.search(np.concatenate([Q, Q[:1]]), 10)         # five queries: the general path
     assert idx.last_path != "direct"
-    _check(D, I, X, Q[:3], 10)
+    _check(D, I, X, np.concatenate([Q, Q[:1]]), 10)
     idx.close()
 
 
@@ -57,7 +57,7 @@ def test_direct_path_ties_ids_soft_deletes_and_few_rows():
     idx = DeviceIndex(d, metric="cosine")
     idx.add(X * 3.0, ids=ids)                                 # cosine: rows are normalised on the way in
     Q = np.stack([X[3000], -X[3000], X[10], X[3000] + 0.1 * X[11]]).astype(np.float32)
-    for nq in (1, 2, 4):
+    for nq in (1, 2, 3, 4):
         for kk in (k, 1000):
             D, I = idx.search(Q[:nq], kk)
             assert idx.last_path == "direct"
@@ -94,7 +94,7 @@ def test_direct_path_skips_nan_rows_and_equals_the_scan_on_ids():
     from oracle import flat
     Dr, Ir = flat.flat_ip_search(Xc, Q, 10)
     assert flat.compare_topk(D, I, Dr, Ir, rtol=RTOL, atol=ATOL) == []
-    # the general path (three queries) returns the same ids for the same queries
-    D3, I3 = idx.search(Q[:3], 10)
-    assert idx.last_path != "direct" and np.array_equal(I3, I[:3])
+    # the general path (five queries) returns the same ids for the same queries
+    D5, I5 = idx.search(np.concatenate([Q, Q[:1]]), 10)
+    assert idx.last_path != "direct" and np.array_equal(I5[:4], I) and np.array_equal(I5[4], I[0])
     idx.close()
