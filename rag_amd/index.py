@@ -316,6 +316,7 @@ class MultiDeviceIndex:
             raise ValueError(f"unknown metric {metric!r} or index kind {kind!r}")
         self.dim, self.metric, self.kind = int(dim), metric, kind
         self.devices = [int(d) for d in devices]
+        self._explicit_ids = False
         ids = (C.c_int * len(self.devices))(*self.devices)
         self._h = C.c_void_p()
         check(lib.rag_multi_create(self.dim, metrics[metric], kinds[kind], len(self.devices), ids, C.byref(self._h)))
@@ -355,6 +356,7 @@ class MultiDeviceIndex:
         if ids_np is not None and ids_np.shape != (x.shape[0],):
             raise ValueError("ids must have one entry per row")
         check(lib.rag_multi_add(self._h, x.shape[0], _ptr(x), _ptr(ids_np)))
+        self._explicit_ids = self._explicit_ids or ids_np is not None
 
     def set_active(self, rows, active: bool) -> None:
         rows = np.ascontiguousarray(rows, dtype=np.int64)
@@ -385,6 +387,15 @@ class MultiDeviceIndex:
         ms = -FLT_MAX if min_score is None else float(min_score)
         check(lib.rag_multi_search(self._h, q.shape[0], _ptr(q), k, ms, int(nprobe), _ptr(m), _ptr(D), _ptr(I)))
         return D, I
+
+    def hybrid_mmr(self, q, topn: int, bm25_rows, bm25_scores, **kw):
+        """Search over every device -> hybrid fusion with the keyword hits (global row positions) -> MMR
+        on the first device, the candidates' vectors fetched from the devices that hold them.  Keyword
+        arguments and result as ``hybrid_mmr``; rows must have been added without explicit ids."""
+        if self._explicit_ids:
+            raise ValueError("hybrid_mmr needs row positions as ids: add rows without explicit ids")
+        return hybrid_mmr_over(self.search, self.reconstruct, len(self), q, topn, bm25_rows, bm25_scores,
+                               device=self.devices[0], **kw)
 
 
 def hybrid_mmr(index: "DeviceIndex", q, topn: int, bm25_rows, bm25_scores, *, fuse_limit: Optional[int] = None,
@@ -476,6 +487,58 @@ def hybrid_mmr(index: "DeviceIndex", q, topn: int, bm25_rows, bm25_scores, *, fu
     res = {"ids": ids[:n_out], "scores": scores[:n_out], "picked": picked[:n_out], "status": status, "n_fused": n_fused}
     for name, a in fused.items():
         res[name] = a[:n_fused]
+    return res
+
+
+def hybrid_mmr_over(search, reconstruct, ntotal: int, q, topn: int, bm25_rows, bm25_scores, *,
+                    fuse_limit: Optional[int] = None, max_results: int = 10, semantic_weight: float = 0.65,
+                    bm25_weight: float = 0.35, mmr_lambda: float = 0.6, mmr_threshold: float = 0.8,
+                    mmr_metric: str = "cosine", min_score: Optional[float] = None, nprobe: int = 1, row_mask=None,
+                    want_fused: bool = False, device: int = 0):
+    """``hybrid_mmr`` for a corpus that is spread over several devices: the search is whatever
+    ``search(q, topn, min_score=, nprobe=, row_mask=)`` answers with global row positions as ids,
+    the candidates' vectors come from ``reconstruct(rows)`` (the <= 1024 fused candidates, fetched
+    from the devices that own them), and fusion (``rag_fuse_maxnorm``) and MMR (``rag_mmr_select``)
+    run on ``device``.  Same arithmetic and order rules as ``rag_index_hybrid_mmr``
+    (vector_db/search_manager.py:938-970, :1023-1101, :1620-1681), same result dictionary."""
+    from . import fusion
+    from .mmr_diversifier import mmr_select_device, normalise_relevance
+    topn = int(topn)
+    bmr = np.ascontiguousarray(bm25_rows, dtype=np.int64).reshape(-1)
+    bms = np.ascontiguousarray(bm25_scores, dtype=np.float64).reshape(-1)
+    if bmr.size != bms.size:
+        raise ValueError("one BM25 score per row")
+    if fuse_limit is None:
+        fuse_limit = min(1024, topn + bmr.size)
+    fuse_limit = int(fuse_limit)
+    if not 1 <= fuse_limit <= 1024 or not 1 <= max_results <= 1024:
+        raise ValueError("fuse_limit and max_results must be in [1, 1024]")
+    q = np.ascontiguousarray(q, dtype=np.float32).reshape(1, -1)
+    D, I = search(q, topn, min_score=min_score, nprobe=nprobe, row_mask=row_mask)
+    D, I = np.asarray(D)[0], np.asarray(I)[0]
+    sem = [(int(r), float(s)) for s, r in zip(D, I) if r >= 0]
+    bm = [(int(r), float(s)) for r, s in zip(bmr, bms) if 0 <= r < ntotal]
+    ranked = fusion.hybrid_fuse(sem, bm, fuse_limit, semantic_weight, bm25_weight)
+    status = 0
+    if ranked is None:                       # a zero maximum: the semantic list as it is (:1098-1101), cut
+        status = 1
+        ranked = [(r, s, s, 0.0, True, False) for r, s in sem][:fuse_limit]
+    f_rows = np.array([t[0] for t in ranked], dtype=np.int64)
+    f_scores = np.array([t[1] for t in ranked], dtype=np.float64)
+    picked: List[int] = []
+    if f_rows.size:
+        emb = np.ascontiguousarray(reconstruct(f_rows), dtype=np.float32)
+        picked = mmr_select_device(emb, normalise_relevance(f_scores.tolist()), mmr_lambda, mmr_threshold, mmr_metric,
+                                   min(int(max_results), f_rows.size), device=device)
+    picked_np = np.array(picked, dtype=np.int32)
+    res = {"ids": f_rows[picked_np] if picked else np.zeros(0, np.int64),
+           "scores": f_scores[picked_np] if picked else np.zeros(0, np.float64),
+           "picked": picked_np, "status": status, "n_fused": int(f_rows.size)}
+    if want_fused:
+        res["fused_rows"] = f_rows
+        res["fused_scores"] = f_scores
+        res["fused_sem"] = np.array([t[2] for t in ranked], dtype=np.float64)
+        res["fused_bm"] = np.array([t[3] for t in ranked], dtype=np.float64)
     return res
 
 

@@ -43,7 +43,7 @@ class ShardedIndex:
     both are the HIP paths of a ``DeviceIndex``; the CPU (gloo) tests of the
     exchange logic inject their own."""
 
-    def __init__(self, local_index=None, *, group=None,
+    def __init__(self, local_index=None, *, group=None, row_base: int = 0,
                  local_search: Optional[Callable] = None, merge: Optional[Callable] = None):
         import torch.distributed as dist
         self.dist = dist
@@ -51,6 +51,7 @@ class ShardedIndex:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.index = local_index
+        self.row_base = int(row_base)        # global position of the local index's first row (hybrid_mmr)
         if local_search is None:
             if local_index is None:
                 raise ValueError("need a local DeviceIndex or a local_search callable")
@@ -124,3 +125,47 @@ class ShardedIndex:
         if was_numpy:
             return Dm.cpu().numpy(), Im.cpu().numpy()
         return Dm, Im
+
+    def gather_rows(self, rows) -> np.ndarray:
+        """Vectors of the global rows ``rows`` on every rank: each rank fills in the rows its index
+        holds, the rest arrive through one all-reduce (a sum in which exactly one rank contributes to
+        an element).  The candidate fetch of the multi-GPU fusion + MMR: <= 1024 rows."""
+        import torch
+        rows = np.ascontiguousarray(rows, dtype=np.int64).reshape(-1)
+        n_local = len(self.index)
+        mine = (rows >= self.row_base) & (rows < self.row_base + n_local)
+        out = np.zeros((rows.size, self.index.dim), dtype=np.float32)
+        if mine.any():
+            out[mine] = self.index.reconstruct(rows[mine] - self.row_base)
+        if self.world > 1:
+            t = torch.from_numpy(out)
+            on_device = self.dist.get_backend(self.group) != "gloo"
+            if on_device:
+                t = t.cuda(self.index.device)
+            self.dist.all_reduce(t, group=self.group)
+            out = t.cpu().numpy()
+        return out
+
+    def hybrid_mmr(self, q, topn: int, bm25_rows, bm25_scores, **kw):
+        """Config "top-N -> hybrid fusion -> MMR" over the sharded corpus: the sharded search, the
+        candidates' vectors gathered from the ranks that own them, fusion and MMR on every rank's own
+        GPU (same inputs, same arithmetic: every rank returns the same answer).  ``row_base`` must be
+        the local index's id base; keyword arguments and result as ``rag_amd.index.hybrid_mmr``."""
+        import torch
+        from .index import hybrid_mmr_over
+        n_total = torch.tensor([len(self.index)], dtype=torch.int64)
+        if self.world > 1:
+            if self.dist.get_backend(self.group) != "gloo":
+                n_total = n_total.cuda(self.index.device)
+            self.dist.all_reduce(n_total, group=self.group)
+
+        def search(qq, k, min_score=None, nprobe=1, row_mask=None):
+            kw2 = {"min_score": min_score, "nprobe": nprobe}
+            if row_mask is not None:
+                kw2["row_mask"] = row_mask
+            qt = torch.from_numpy(qq).cuda(self.index.device)
+            D, I = self.search(qt, k, **kw2)
+            return D.cpu().numpy(), I.cpu().numpy()
+
+        return hybrid_mmr_over(search, self.gather_rows, int(n_total.item()), q, topn, bm25_rows, bm25_scores,
+                               device=self.index.device, **kw)

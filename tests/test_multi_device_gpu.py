@@ -115,3 +115,43 @@ def test_thread_staging_memory_can_be_handed_back():
     assert np.array_equal(I0, I1) and np.array_equal(I0, I2) and np.array_equal(D0, D2)
     assert free0 - free1 >= 8 << 20 and free2 - free1 >= 8 << 20
     idx.close()
+
+
+def test_multi_device_hybrid_mmr_equals_one_index():
+    """top-N -> hybrid fusion -> MMR with the corpus dealt over several shards: candidates' vectors come
+    from the shards that hold them, and the answer is that of the one-index call bit for bit."""
+    from rag_amd import DeviceIndex, MultiDeviceIndex
+    from rag_amd.index import hybrid_mmr
+    rng = np.random.default_rng(31)
+    n, d = 120_000, 256
+    cent = rng.standard_normal((30, d))
+    X = cent[rng.integers(0, 30, n)] + 0.2 * rng.standard_normal((n, d))
+    X = (X / np.linalg.norm(X, axis=1, keepdims=True)).astype(np.float32)
+    one = DeviceIndex(d, metric="cosine")
+    one.add(X)
+    multi = MultiDeviceIndex(d, [0, 0, 0], metric="cosine")
+    multi.add(X[:50_000])
+    multi.add(X[50_000:])
+    assert min(multi.shard_rows()) > 32768                     # every shard on the scan path, like the one index
+    for trial in range(3):
+        q = (cent[trial] / np.linalg.norm(cent[trial])).astype(np.float32)
+        _, I = one.search(q, 200)
+        bm_rows = np.concatenate([rng.choice(I[0], 50, replace=False), rng.integers(0, n, 50), [-1, n]])
+        bm_scores = rng.gamma(2.0, 2.0, size=bm_rows.size)
+        for kw in ({"mmr_lambda": 0.5, "mmr_threshold": 0.8}, {"mmr_lambda": 0.3, "mmr_threshold": 0.5, "max_results": 30},
+                   {"mmr_metric": "euclidean", "mmr_threshold": 0.4, "fuse_limit": 64}):
+            a = multi.hybrid_mmr(q, 200, bm_rows, bm_scores, want_fused=True, **kw)
+            b = hybrid_mmr(one, q, 200, bm_rows, bm_scores, want_fused=True, **kw)
+            assert a["status"] == b["status"] == 0 and a["n_fused"] == b["n_fused"] and len(a["ids"]) > 0
+            for name in ("ids", "scores", "picked", "fused_rows", "fused_scores", "fused_sem", "fused_bm"):
+                assert np.array_equal(np.asarray(a[name]), np.asarray(b[name])), (trial, kw, name)
+    # a zero maximum on the keyword side: the semantic list, on both
+    a = multi.hybrid_mmr(q, 50, [1, 2, 3], [0.0, 0.0, 0.0])
+    b = hybrid_mmr(one, q, 50, [1, 2, 3], [0.0, 0.0, 0.0])
+    assert a["status"] == b["status"] == 1 and np.array_equal(a["ids"], b["ids"]) and np.array_equal(a["scores"], b["scores"])
+    with_ids = MultiDeviceIndex(d, [0, 0], metric="ip")
+    with_ids.add(X[:2000], ids=np.arange(2000, dtype=np.int64) + 7)
+    with pytest.raises(ValueError):
+        with_ids.hybrid_mmr(q, 10, [], [])
+    for ix in (one, multi, with_ids):
+        ix.close()

@@ -60,6 +60,24 @@ def _worker(rank, world, port, out_dir):
         bad = flat.compare_topk(D.cpu().numpy(), I.cpu().numpy(), Dr, Ir, rtol=RTOL, atol=ATOL)
         if bad:
             problems.append(("flat", nq, k, idx.last_path, bad[:3]))
+    # top-200 -> hybrid fusion -> MMR over the shards = the same call on one index over all rows
+    from rag_amd.index import hybrid_mmr
+    whole = DeviceIndex(d, metric="ip", device=0)
+    whole.add(X)
+    sh.row_base = lo
+    q = (X[5] + 0.3 * X[77]).astype(np.float32)
+    bm_rows = np.concatenate([rng.integers(0, n, 60), [5, 140_000, 77, -3, n + 9]])
+    bm_scores = rng.gamma(2.0, 2.0, size=bm_rows.size)
+    for kw in ({"mmr_lambda": 0.5, "mmr_threshold": 0.3}, {"mmr_lambda": 0.7, "mmr_threshold": 0.0, "mmr_metric": "dot_product",
+                                                            "fuse_limit": 80, "max_results": 25}):
+        a = sh.hybrid_mmr(q, 200, bm_rows, bm_scores, want_fused=True, **kw)
+        b = hybrid_mmr(whole, q, 200, bm_rows, bm_scores, want_fused=True, **kw)
+        for name in ("ids", "scores", "picked", "fused_rows", "fused_scores", "fused_sem", "fused_bm"):
+            if not np.array_equal(np.asarray(a[name]), np.asarray(b[name])):
+                problems.append(("hybrid_mmr", name, repr(kw)))
+        if a["status"] != b["status"] or a["n_fused"] != b["n_fused"] or len(a["ids"]) == 0:
+            problems.append(("hybrid_mmr", "status / counts", repr(kw)))
+    whole.close()
     idx.close()
 
     # IVF shards with shared centroids = one IVF index over all rows
