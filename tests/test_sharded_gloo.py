@@ -52,6 +52,21 @@ def _worker(rank, world, port, out_dir):
     D, I = sh.search(Q, k)
     Dr, Ir = flat.flat_ip_search(X, Q, k)
     ok = np.array_equal(I, Ir) and np.array_equal(D, Dr)
+
+    # the candidate fetch of the sharded fusion + MMR: every rank ends with the vectors of rows it does not hold
+    class LocalRows:
+        dim, device = d, 0
+
+        def __len__(self):
+            return hi - lo
+
+        def reconstruct(self, rows):
+            assert ((rows >= 0) & (rows < hi - lo)).all()          # only rows of this shard are asked for
+            return X[lo:hi][rows]
+
+    sh2 = ShardedIndex(LocalRows(), row_base=lo, local_search=local_search, merge=merge)
+    want_rows = np.array([4000, 10, 0, n - 1, 2501, 2502, 10])      # the same request on every rank
+    ok = ok and np.array_equal(sh2.gather_rows(want_rows), X[want_rows]) and sh2.gather_rows([]).shape == (0, d)
     np.save(os.path.join(out_dir, f"ok_{rank}.npy"), np.array([ok, sh.world == world]))
     dist.barrier()
     dist.destroy_process_group()
