@@ -220,6 +220,12 @@ int rag_fuse_maxnorm(int64_t n, const double* a, const double* b, const uint8_t*
 int rag_mmr_select(int64_t n, int d, const void* emb, int emb_is_f64, const double* rel,
                    double lambda, double similarity_threshold, int metric, int max_results,
                    int device, int32_t* out_idx, int32_t* n_out);
+/* vector_db/mmr_diversifier.py:291-319 compute_similarity_matrix: S_out[i*n + j] (n x n fp64, row-major) =
+ * similarity of rows i and j under RAG_MMR_COSINE (rows divided by their norm, a zero row stays zero),
+ * RAG_MMR_DOT, or RAG_MMR_EUCLIDEAN (1 / (1 + distance)); the values the MMR selection itself uses, the
+ * matrix symmetric bit for bit.  n <= 4096. */
+int rag_similarity_matrix(int64_t n, int d, const void* emb, int emb_is_f64, int metric, int device,
+                          double* S_out);
 /* same, embeddings taken from rows of an index (no host copy of vectors; replaces the vector
  * fetch of vector_db/search_manager.py:1699-1727).  rows[i] are ROW POSITIONS (insertion order,
  * 0 .. ntotal-1), not ids: with an id base or explicit ids the caller maps ids back to positions.

@@ -6,6 +6,7 @@ TEST INFRASTRUCTURE ONLY.  Runs in the build container only (needs
 outputs), never the reference's source.  Usage:
 
     python oracle/gen_golden.py            # rewrites tests/golden/
+    python oracle/gen_golden.py mmr_analysis.json      # only the named files
 
 How the reference is loaded: its packages cannot be imported whole
 (``api/__init__.py`` and ``database/__init__.py`` pull in FastAPI routes and
@@ -386,6 +387,47 @@ def gen_mmr(mods, rng):
     return {"source": "vector_db/mmr_diversifier.py:65-289 MMRDiversifier.diversify", "cases": cases}
 
 
+def gen_mmr_analysis(mods, rng):
+    """compute_similarity_matrix and analyze_diversity of the reference class."""
+    M = mods["mmr"].MMRDiversifier
+    SR = mods["schemas"].SearchResult
+    sims, sets = [], {"none": []}
+    e = _clustered(rng, 14, 16, 3, 0.1)
+    e[4] = 0.0                                   # a zero row stays zero under cosine
+    e[9] = e[2]                                  # an exact duplicate
+    wide = _clustered(rng, 9, 300, 2, 0.3)       # rows wider than a wave's 64 lanes x 4
+    unit32 = (e[:6] / np.maximum(np.linalg.norm(e[:6], axis=1, keepdims=True), 1e-30)).astype(np.float32)
+    for name, emb in (("clustered 14x16 with a zero row and a duplicate", e), ("9x300", wide), ("fp32 rows", unit32),
+                      ("one row", e[:1])):
+        for metric in ("cosine", "dot_product", "euclidean", "manhattan"):
+            m = M(similarity_metric=metric)
+            S = m.compute_similarity_matrix([np.asarray(r) for r in emb])
+            sims.append({"note": name, "metric": metric, "dtype": str(emb.dtype), "set": name,
+                         "expected": [[float(v) for v in r] for r in S]})
+        sets[name] = [[float(v) for v in r] for r in emb]
+    empty = M().compute_similarity_matrix([])
+    sims.append({"note": "no embeddings", "metric": "cosine", "dtype": "float64", "set": "none",
+                 "expected": [float(v) for v in empty], "expected_shape": list(empty.shape)})
+    div = []
+    words = "dense retrieval inner product search keyword matrix cores".split()
+
+    def results(n, docs):
+        return [{"document_id": docs[i % len(docs)], "chunk_id": f"c{i}", "score": float(rng.uniform()),
+                 "text": " ".join(rng.choice(words, int(rng.integers(0, 12))))} for i in range(n)]
+
+    for note, rs, as_objects in (("dicts, three documents", results(10, [1, 2, 3]), False),
+                                 ("SearchResult objects, str and int ids", results(7, ["a", 5, "b", 5]), True),
+                                 ("one result", results(1, [9]), False),
+                                 ("dicts without text or document_id", [{"score": 0.5}, {"score": 0.1, "text": "abc"}], False)):
+        given = [SR(**r) for r in rs] if as_objects else rs
+        out = M().analyze_diversity(given)
+        div.append({"note": note, "as_objects": as_objects, "results": rs,
+                    "expected": {k: (float(v) if isinstance(v, (float, np.floating)) else v) for k, v in out.items()}})
+    div.append({"note": "no results", "as_objects": False, "results": [], "expected": M().analyze_diversity([])})
+    return {"source": "vector_db/mmr_diversifier.py:291-366 MMRDiversifier.compute_similarity_matrix / analyze_diversity",
+            "embedding_sets": sets, "similarity": sims, "diversity": div}
+
+
 # --------------------------------------------------------------------- cosine scan
 def gen_cosine_scan(mods, rng):
     E = mods["fb"].EmbeddedVectorDB
@@ -422,8 +464,12 @@ def main():
         "bm25.json": gen_bm25,
         "mmr.json": gen_mmr,
         "cosine_scan.json": gen_cosine_scan,
+        "mmr_analysis.json": gen_mmr_analysis,
     }
+    only = set(sys.argv[1:])                     # file names to (re)write; none = all
     for name, fn in gens.items():
+        if only and name not in only:
+            continue
         rng = np.random.default_rng(abs(hash(name)) % (2 ** 31) if False else sum(map(ord, name)))
         data = fn(mods, rng)
         data["generated_by"] = "oracle/gen_golden.py"

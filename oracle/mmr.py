@@ -118,3 +118,36 @@ def mmr_select_fast(E, scores, lambda_param, max_results=None,
         alive[best] = False
         maxsim = np.maximum(maxsim, simcol(best))
     return out
+
+
+def similarity_matrix(embeddings, metric="cosine"):
+    """mmr_diversifier.py:291-319 compute_similarity_matrix: no embeddings -> an empty 1-D array; else
+    the n x n matrix of the stacked rows under 'cosine' (row-normalised product), 'dot_product'
+    (plain product), 'euclidean' (1 / (1 + distance), sklearn's distances: the diagonal is exactly
+    zero, the rest sqrt of the clamped |x|^2 - 2 x.y + |y|^2); anything else = cosine."""
+    if not embeddings:
+        return np.array([])
+    E = np.vstack(embeddings)
+    if metric == "dot_product":
+        return np.dot(E, E.T)
+    if metric == "euclidean":
+        sq = np.einsum("ij,ij->i", E, E)
+        d2 = sq[:, None] - 2.0 * (E @ E.T) + sq[None, :]
+        np.maximum(d2, 0.0, out=d2)
+        np.fill_diagonal(d2, 0.0)
+        return 1.0 / (1.0 + np.sqrt(d2))
+    return _cosine_rows(E, E)
+
+
+def analyze_diversity(results):
+    """mmr_diversifier.py:321-366 analyze_diversity on dict results ('text', 'document_id'): counts,
+    the share of distinct documents, mean and variance of the text lengths."""
+    if not results:
+        return {"error": "No results provided"}
+    texts = [r.get("text", "") for r in results]
+    unique = len(set(r.get("document_id") for r in results))
+    lens = [len(t) for t in texts]
+    return {"total_results": len(results), "unique_documents": unique,
+            "document_diversity_ratio": unique / len(results),
+            "avg_text_length": float(np.mean(lens)) if texts else 0,
+            "text_length_variance": float(np.var(lens)) if texts else 0}

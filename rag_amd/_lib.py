@@ -65,6 +65,7 @@ SIGNATURES = {
     "rag_fuse_weighted": (_i32, [_i64, _vp, _vp, _f64, _f64, _i32, _f64, _i32, _vp, _vp, _vp]),
     "rag_fuse_maxnorm": (_i32, [_i64, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _f64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "rag_mmr_select": (_i32, [_i64, _i32, _vp, _i32, _vp, _f64, _f64, _i32, _i32, _i32, _vp, _vp]),
+    "rag_similarity_matrix": (_i32, [_i64, _i32, _vp, _i32, _i32, _i32, _vp]),
     "rag_mmr_select_rows": (_i32, [_vp, _i64, _vp, _vp, _f64, _f64, _i32, _i32, _vp, _vp]),
     "rag_index_hybrid_mmr": (_i32, [_vp, _vp, _i32, _f32, _i32, _vp, _i64, _vp, _vp, _f64, _f64, _i32, _f64, _f64, _i32,
                                     _i32, _vp]),

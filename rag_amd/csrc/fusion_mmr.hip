@@ -871,8 +871,8 @@ static int mmr_sim_limit() {
     return lim;
 }
 
-// enqueue prepare + pair matrix + selection for at most n_max candidates (p.En, p.rel, p.n_dev set by the caller)
-static int enqueue_mmr_sim(const MmrArgs& p, int n_max, double* S, MmrSelArgs sel, hipStream_t s) {
+// enqueue the row preparation and the pair matrix S[n_max][n_max] of at most n_max candidates (p.En, p.n_dev set by the caller)
+static void enqueue_pair_matrix(const MmrArgs& p, int n_max, double* S, hipStream_t s) {
     MmrState none = {};
     hipLaunchKernelGGL(mmr_prepare_kernel, dim3((unsigned)n_max), dim3(64), 0, s, p, none);
     static_assert(SIM_TC == SIM_TS, "square tiles: the lower triangle is enumerated tile by tile");
@@ -884,6 +884,11 @@ static int enqueue_mmr_sim(const MmrArgs& p, int n_max, double* S, MmrSelArgs se
     else if (jl <= 12) hipLaunchKernelGGL(mmr_simmat_kernel<12>, grid, dim3(256), 0, s, p.En, p.n_dev, n_max, p.d, p.metric, S, n_max);
     else if (jl <= 16) hipLaunchKernelGGL(mmr_simmat_kernel<16>, grid, dim3(256), 0, s, p.En, p.n_dev, n_max, p.d, p.metric, S, n_max);
     else hipLaunchKernelGGL(mmr_simmat_kernel<0>, grid, dim3(256), 0, s, p.En, p.n_dev, n_max, p.d, p.metric, S, n_max);
+}
+
+// enqueue prepare + pair matrix + selection for at most n_max candidates (p.En, p.rel, p.n_dev set by the caller)
+static int enqueue_mmr_sim(const MmrArgs& p, int n_max, double* S, MmrSelArgs sel, hipStream_t s) {
+    enqueue_pair_matrix(p, n_max, S, s);
     sel.S = S;
     sel.ldS = n_max;
     sel.rel = p.rel;
@@ -1115,6 +1120,35 @@ int rag_mmr_select(int64_t n, int d, const void* emb, int emb_is_f64, const doub
     if (n > 0 && !emb) return fail(RAG_ERR_INVALID, "emb is NULL");
     return run_mmr(device, n, d, emb, emb_is_f64, nullptr, 0, nullptr, rel, lambda, similarity_threshold, metric,
                    max_results, out_idx, n_out);
+}
+
+int rag_similarity_matrix(int64_t n, int d, const void* emb, int emb_is_f64, int metric, int device, double* S_out) {
+    if (n < 0 || n > MMR_MAX_N) return fail(RAG_ERR_INVALID, "the similarity matrix handles 0.." + std::to_string(MMR_MAX_N) + " rows");
+    if (n == 0) return RAG_OK;
+    if (d < 1) return fail(RAG_ERR_INVALID, "d < 1");
+    if (!emb || !S_out) return fail(RAG_ERR_INVALID, "NULL buffer");
+    if (metric != RAG_MMR_COSINE && metric != RAG_MMR_DOT && metric != RAG_MMR_EUCLIDEAN) return fail(RAG_ERR_INVALID, "unknown MMR metric");
+    int prev = 0;
+    RAG_HIP_CHECK(hipGetDevice(&prev));
+    if (prev != device) RAG_HIP_CHECK(hipSetDevice(device));
+    struct Restore { int p, d; ~Restore() { if (p != d) (void)hipSetDevice(p); } } restore{prev, device};
+    Workspace& ws = thread_workspace(TWS_FUSE, device);
+    const size_t esz = emb_is_f64 ? 8 : 4;
+    const size_t eb = al256((size_t)n * d * esz), enb = al256((size_t)n * d * 8), sb = al256((size_t)n * n * 8);
+    // [embeddings | rows as the similarity uses them | pair matrix]
+    if (int rc = ws.ensure(eb + enb + sb)) return rc;
+    char* base = static_cast<char*>(ws.ptr);
+    hipStream_t s = nullptr;
+    RAG_HIP_CHECK(hipMemcpyAsync(base, emb, (size_t)n * d * esz, hipMemcpyHostToDevice, s));
+    MmrArgs p = {};
+    p.emb = base; p.emb_is_f64 = emb_is_f64; p.En = reinterpret_cast<double*>(base + eb);
+    p.metric = metric; p.n = (int)n; p.d = d;
+    double* S = reinterpret_cast<double*>(base + eb + enb);
+    enqueue_pair_matrix(p, (int)n, S, s);
+    RAG_HIP_CHECK(hipGetLastError());
+    RAG_HIP_CHECK(hipMemcpyAsync(S_out, S, (size_t)n * n * 8, hipMemcpyDeviceToHost, s));
+    RAG_HIP_CHECK(hipStreamSynchronize(s));
+    return RAG_OK;
 }
 
 int rag_mmr_select_rows(rag_index_t* h, int64_t n, const int64_t* rows, const double* rel, double lambda,

@@ -44,6 +44,19 @@ def mmr_select_device(embeddings: np.ndarray, relevance: Sequence[float], lambda
     return out[:n_out.value].tolist()
 
 
+def similarity_matrix_device(embeddings: np.ndarray, metric: str, device: int = 0) -> np.ndarray:
+    """Pair similarities of the rows of a dense [n, d] matrix (fp32 or fp64) in fp64 on the GPU: the
+    values the MMR selection uses (vector_db/mmr_diversifier.py:291-319)."""
+    emb = np.ascontiguousarray(embeddings)
+    if emb.dtype not in (np.float32, np.float64):
+        emb = emb.astype(np.float64)
+    n, d = emb.shape
+    out = np.empty((n, n), dtype=np.float64)
+    check(lib.rag_similarity_matrix(n, d, emb.ctypes.data_as(C.c_void_p), 1 if emb.dtype == np.float64 else 0,
+                                    _METRICS.get(metric, _lib.MMR_COSINE), int(device), out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
 def mmr_select_rows(index, rows: Sequence[int], relevance: Sequence[float], lambda_param: float,
                     similarity_threshold: float, metric: str, max_results: int) -> List[int]:
     """Same selection with the embeddings taken from rows of a ``DeviceIndex``
@@ -148,6 +161,39 @@ class MMRDiversifier:
         except Exception as e:      # vector_db/mmr_diversifier.py:117-120
             logger.error(f"MMR diversification failed: {e}")
             return results[:max_res]
+
+    def compute_similarity_matrix(self, embeddings: List[np.ndarray]) -> np.ndarray:
+        """vector_db/mmr_diversifier.py:291-319: the n x n similarity matrix of the stacked embeddings under
+        this diversifier's metric (an unknown metric counts as cosine); no embeddings -> an empty array."""
+        if not embeddings:
+            return np.array([])
+        return similarity_matrix_device(np.vstack(embeddings), self.similarity_metric, self.device)
+
+    def analyze_diversity(self, results: List[Union[Any, Dict[str, Any]]]) -> Dict[str, Any]:
+        """vector_db/mmr_diversifier.py:321-366: counts of a result set -- results, distinct documents and
+        their ratio, mean and variance of the text lengths.  Host bookkeeping; errors come back as
+        ``{"error": ...}`` like the reference's."""
+        try:
+            if not results:
+                return {"error": "No results provided"}
+            texts = []
+            for r in results:
+                if isinstance(r, dict):
+                    texts.append(r.get("text", ""))
+                elif hasattr(r, "text"):
+                    texts.append(r.text)
+            unique_documents = len(set(r.get("document_id") if isinstance(r, dict) else r.document_id for r in results))
+            lengths = [len(t) for t in texts]
+            return {
+                "total_results": len(results),
+                "unique_documents": unique_documents,
+                "document_diversity_ratio": unique_documents / len(results),
+                "avg_text_length": np.mean(lengths) if texts else 0,
+                "text_length_variance": np.var(lengths) if texts else 0,
+            }
+        except Exception as e:
+            logger.error(f"Diversity analysis failed: {e}")
+            return {"error": str(e)}
 
     async def __aenter__(self):
         return self

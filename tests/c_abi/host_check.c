@@ -176,6 +176,11 @@ int main(void) {
     int32_t pick[5], npick = 0;
     CHECK(rag_mmr_select_rows(h, 5, cand, rel, 1.0, 0.8, RAG_MMR_COSINE, 3, pick, &npick) == RAG_OK, "mmr rows");
     CHECK(npick == 3 && pick[0] == 1 && pick[1] == 3 && pick[2] == 4, "mmr order %d %d %d", pick[0], pick[1], pick[2]);
+    /* pair similarities of the two reconstructed rows: unit rows, so the cosine diagonal is 1 and the matrix symmetric */
+    double S2[4];
+    CHECK(rag_similarity_matrix(2, d, back, 0, RAG_MMR_COSINE, 0, S2) == RAG_OK, "similarity matrix");
+    CHECK(fabs(S2[0] - 1.0) < 1e-12 && fabs(S2[3] - 1.0) < 1e-12 && S2[1] == S2[2] && fabs(S2[1]) < 1.0, "similarity values %g %g", S2[0], S2[1]);
+    CHECK(rag_similarity_matrix(2, d, back, 0, 7, 0, S2) == RAG_ERR_INVALID, "unknown similarity metric accepted");
     CHECK(rag_index_free(h) == RAG_OK, "free");
 
     /* IVF: every list probed = the exhaustive answer */

@@ -125,6 +125,51 @@ def test_mmr_rows_of_index_and_oracle_at_config_size():
     idx.close()
 
 
+def test_similarity_matrix_and_diversity_golden(golden):
+    """MMRDiversifier.compute_similarity_matrix on the device against the reference's outputs
+    (vector_db/mmr_diversifier.py:291-319) and analyze_diversity (:321-366) on dicts and result objects.
+    The device computes in fp64 whatever the input type (as the MMR selection does); the reference's
+    result for fp32 rows is an fp32 matrix and its euclidean values carry sklearn's ~1e-7 cancellation
+    noise: those are compared to 1e-6, everything else to 1e-12 of the largest entry."""
+    from oracle import mmr as ommr
+    from rag_amd.mmr_diversifier import MMRDiversifier
+    from rag_amd.schemas import SearchResult
+    data = golden("mmr_analysis.json")
+    for c in data["similarity"]:
+        E = [np.array(r, dtype=c["dtype"]) for r in data["embedding_sets"][c["set"]]]
+        m = MMRDiversifier(similarity_metric=c["metric"])
+        S = m.compute_similarity_matrix(E)
+        want = np.array(c["expected"])
+        assert S.shape == want.shape and S.dtype == np.float64, (c["note"], S.shape, want.shape)
+        if not want.size:
+            continue
+        loose = c["metric"] == "euclidean" or c["dtype"] == "float32"
+        tol = (1e-6 if loose else 1e-12) * max(1.0, float(np.abs(want).max()))
+        assert np.abs(S - want).max() <= tol, (c["note"], c["metric"], float(np.abs(S - want).max()))
+        assert np.array_equal(S, S.T)                                   # symmetric bit for bit
+        if c["metric"] == "euclidean":
+            assert np.all(np.diag(S) == 1.0)                            # a row is at distance 0 from itself
+    for c in data["diversity"]:
+        given = [SearchResult(**r) for r in c["results"]] if c["as_objects"] else c["results"]
+        got = MMRDiversifier().analyze_diversity(given)
+        assert got == c["expected"], (c["note"], got)
+    # sizes past one tile, rows wider than the register path, fp64 oracle on the same rows
+    rng = np.random.default_rng(3)
+    for n, d in ((1, 5), (9, 64), (130, 384), (257, 768), (40, 1100), (600, 33)):
+        E = rng.standard_normal((n, d))
+        E[n // 2] = E[0]
+        for metric in ("cosine", "dot_product", "euclidean"):
+            S = MMRDiversifier(similarity_metric=metric).compute_similarity_matrix(list(E))
+            want = ommr.similarity_matrix(list(E), metric)
+            # the expansion's cancellation error in a distance grows with the rows' norms (~sqrt(eps) * |x|)
+            tol = 1e-7 * float(np.linalg.norm(E, axis=1).max()) if metric == "euclidean" else 1e-12 * max(1.0, float(np.abs(want).max()))
+            assert S.shape == (n, n) and np.abs(S - want).max() <= tol, (n, d, metric, float(np.abs(S - want).max()))
+            assert np.array_equal(S, S.T)
+            if metric == "euclidean":                                   # against sums of squared differences: no cancellation
+                direct = np.stack([1.0 / (1.0 + np.sqrt(((E - E[i]) ** 2).sum(axis=1))) for i in range(n)])
+                assert np.abs(S - direct).max() <= 1e-12, (n, d, float(np.abs(S - direct).max()))
+
+
 def test_rerank_blend_matches_reference_formula():
     """(1-w)*clip(orig) + w*clip(rerank), threshold on the raw rerank score, stable sort, top_k:
     bit-exact against the oracle's restatement of base_reranker.py:256-280 and the ordering of

@@ -110,6 +110,25 @@ def test_mmr_fast_equals_loop(golden):
         assert got == c["expected"], c["note"]
 
 
+def test_similarity_matrix_and_diversity_match_reference(golden):
+    """MMRDiversifier.compute_similarity_matrix / analyze_diversity.  Cosine and dot products agree to
+    the last bits of an fp64 matrix product; the reference's euclidean values come out of sklearn's
+    |x|^2 - 2 x.y + |y|^2 expansion, whose cancellation leaves ~1e-7 in a distance (its value for two
+    identical rows is 0.99999992, not 1), so that metric is compared to 1e-6."""
+    data = golden("mmr_analysis.json")
+    for c in data["similarity"]:
+        E = [np.array(r, dtype=c["dtype"]) for r in data["embedding_sets"][c["set"]]]
+        S = mmr.similarity_matrix(E, c["metric"])
+        want = np.array(c["expected"])
+        assert S.shape == want.shape, c["note"]
+        if "expected_shape" in c:
+            assert list(S.shape) == c["expected_shape"]
+        tol = 1e-6 if c["metric"] == "euclidean" else 1e-12
+        assert np.allclose(S, want, rtol=0, atol=tol * max(1.0, float(np.abs(want).max()) if want.size else 1.0)), (c["note"], c["metric"])
+    for c in data["diversity"]:
+        assert mmr.analyze_diversity(c["results"]) == c["expected"], c["note"]
+
+
 def test_cosine_scan_matches_reference_and_flat_ip(golden):
     data = golden("cosine_scan.json")
     for c in data["cases"]:
