@@ -32,10 +32,19 @@ enum rag_status {
     RAG_ERR_UNSUPPORTED = 4   /* valid request this build does not cover */
 };
 
-/* vector_db/search_optimizer.py:33-36 MetricType.  COSINE rows are normalised
- * when added and queries when searched (what a Qdrant COSINE collection does),
- * after which the scan is an inner product. */
-enum rag_metric { RAG_METRIC_IP = 0, RAG_METRIC_COSINE = 1 };
+/* vector_db/search_optimizer.py:33-36 MetricType (mapped to a distance at :100-109).  COSINE rows
+ * are normalised when added and queries when searched (what a Qdrant COSINE collection does),
+ * after which the scan is an inner product.
+ * L2 (MetricType.EUCLIDEAN; FAISS IndexFlatL2 semantics; FLAT indexes only): a search returns
+ * SQUARED Euclidean distances, nearest first (equal distances: lower row first), empty slots as
+ * I = -1 / D = FLT_MAX, and its min_score argument is the LARGEST squared distance returned
+ * (negative: no limit) -- Qdrant reads score_threshold as an upper bound for its Euclid distance
+ * (call site :213-222).  The rows are ranked on the same scan / matrix-core kernels by
+ * q.x - |x|^2 / 2 (a row stores -|x|^2 / 2 in an extra column, its stride is a multiple of 32
+ * floats); the k kept rows are then re-scored as sums of squared fp32 differences, so a row equal
+ * to the query is at distance exactly 0.  Entry points that rank by similarity (segment search, the
+ * fusion + MMR call, rag_multi_*, adopt, the bf16 first pass) return RAG_ERR_UNSUPPORTED. */
+enum rag_metric { RAG_METRIC_IP = 0, RAG_METRIC_COSINE = 1, RAG_METRIC_L2 = 2 };
 
 /* FLAT = exhaustive scan (FAISS IndexFlatIP semantics); IVF = coarse lists
  * (FAISS IndexIVFFlat semantics with an inner-product flat quantiser). */

@@ -12,6 +12,8 @@ What is restated here
   against FAISS itself; anchored on the reference's call site
   ``vector_db/search_optimizer.py:213-222`` (limit, score_threshold) and on
   ``embedded_cosine_scan`` below for unit vectors.
+* ``flat_l2_search`` -- FAISS ``IndexFlatL2`` semantics (squared distances ascending) for the
+  ``MetricType.EUCLIDEAN`` a ``SearchConfig`` may name (vector_db/search_optimizer.py:33-35,104-105).
 * ``embedded_cosine_scan`` -- the reference's only in-repo exact scan,
   ``utils/service_fallbacks.py:101-144`` (fp32 dot / (norm*norm), 0 when a norm is
   0, Python stable sort descending, ``[:limit]``).
@@ -39,7 +41,7 @@ def l2_normalize_rows(x: np.ndarray) -> np.ndarray:
 
 
 def flat_ip_search(X, Q, k, min_score=None, row_mask=None, ids=None, block=65536,
-                   precise=True):
+                   precise=True, _scores=None):
     """Exact inner-product top-k over fp32 data.
 
     X: [n, d] float32 rows; Q: [nq, d]; returns (D float32 [nq,k], I int64 [nq,k]).
@@ -68,7 +70,9 @@ def flat_ip_search(X, Q, k, min_score=None, row_mask=None, ids=None, block=65536
     Q64 = Q.astype(np.float64) if precise else None
     for b0 in range(0, n, block):
         b1 = min(n, b0 + block)
-        if precise:
+        if _scores is not None:
+            S = _scores(b0, b1)                 # another similarity over the same selection rule (flat_l2_search)
+        elif precise:
             S = (Q64 @ X[b0:b1].astype(np.float64).T).astype(np.float32)
         else:
             S = Q @ X[b0:b1].T                  # fp32 sgemm / sgemv
@@ -115,6 +119,38 @@ def flat_ip_search(X, Q, k, min_score=None, row_mask=None, ids=None, block=65536
         ids = np.asarray(ids, dtype=np.int64)
         I = np.where(I >= 0, ids[np.clip(I, 0, None)], -1)
     return D, I
+
+
+def flat_l2_search(X, Q, k, max_dist2=None, row_mask=None, ids=None, block=65536):
+    """FAISS ``IndexFlatL2.search`` semantics: exact SQUARED Euclidean distance of every query to every
+    stored row, the k nearest per query in ascending order, unfilled slots ``I = -1`` / ``D = FLT_MAX``
+    (ties: lower id first, as in ``flat_ip_search``).  ``max_dist2``: rows farther than this are dropped
+    (Qdrant's ``score_threshold`` for ``Distance.EUCLID`` is an upper bound on the distance, the call
+    site being vector_db/search_optimizer.py:213-222).  Distances are fp64 sums |q|^2 - 2 q.x + |x|^2
+    rounded once to fp32 and clamped at 0.  **Parity unpinned**: the reference holds no L2 output
+    (its collections are COSINE, storage_manager.py:132,203) and FAISS is not installed."""
+    X = np.ascontiguousarray(X, dtype=np.float32)
+    Q = np.ascontiguousarray(Q, dtype=np.float32)
+    if Q.ndim == 1:
+        Q = Q[None, :]
+    Q64 = Q.astype(np.float64)
+    qn = np.einsum("ij,ij->i", Q64, Q64)
+
+    def neg_dist(b0, b1):
+        Xb = X[b0:b1].astype(np.float64)
+        d2 = qn[:, None] - 2.0 * (Q64 @ Xb.T) + np.einsum("ij,ij->i", Xb, Xb)[None, :]
+        return (-np.maximum(d2, 0.0)).astype(np.float32)
+
+    S, I = flat_ip_search(X, Q, k, min_score=None if max_dist2 is None else -float(max_dist2), row_mask=row_mask, ids=ids,
+                          block=block, _scores=neg_dist)
+    D = np.where(I >= 0, -S, FLT_MAX).astype(np.float32)
+    return D, I
+
+
+def compare_topk_l2(D_test, I_test, D_ref, I_ref, rtol=1e-5, atol=1e-6):
+    """``compare_topk`` for ascending distance lists: the same rule on the negated distances."""
+    neg = lambda D, I: np.where(np.asarray(I) >= 0, -np.asarray(D, dtype=np.float64), -float(FLT_MAX))
+    return compare_topk(neg(D_test, I_test), I_test, neg(D_ref, I_ref), I_ref, rtol=rtol, atol=atol)
 
 
 def rescore_f64(X, Q, I):

@@ -23,7 +23,7 @@ class RagHipError(RuntimeError):
 
 
 RAG_OK, RAG_ERR_INVALID, RAG_ERR_HIP, RAG_ERR_OOM, RAG_ERR_UNSUPPORTED = 0, 1, 2, 3, 4
-METRIC_IP, METRIC_COSINE = 0, 1
+METRIC_IP, METRIC_COSINE, METRIC_L2 = 0, 1, 2
 KIND_FLAT, KIND_IVF = 0, 1
 MMR_COSINE, MMR_DOT, MMR_EUCLIDEAN = 0, 1, 2
 

@@ -352,8 +352,9 @@ int rag_index_create(int dim, int metric, int kind, int device, rag_index_t** ou
     if (!out) return fail(RAG_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (dim < 1 || dim > 65536) return fail(RAG_ERR_INVALID, "dim must be in [1, 65536]");
-    if (metric != RAG_METRIC_IP && metric != RAG_METRIC_COSINE) return fail(RAG_ERR_INVALID, "unknown metric");
+    if (metric != RAG_METRIC_IP && metric != RAG_METRIC_COSINE && metric != RAG_METRIC_L2) return fail(RAG_ERR_INVALID, "unknown metric");
     if (kind != RAG_KIND_FLAT && kind != RAG_KIND_IVF) return fail(RAG_ERR_INVALID, "unknown index kind");
+    if (metric == RAG_METRIC_L2 && kind != RAG_KIND_FLAT) return fail(RAG_ERR_UNSUPPORTED, "the L2 metric needs a FLAT index");
     int ndev = 0;
     RAG_HIP_CHECK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(RAG_ERR_INVALID, "device " + std::to_string(device) + " out of range (" + std::to_string(ndev) + " visible)");
@@ -361,7 +362,9 @@ int rag_index_create(int dim, int metric, int kind, int device, rag_index_t** ou
     if (!g.ok) return fail(RAG_ERR_HIP, "hipSetDevice failed");
     rag_index* h = new rag_index();
     h->dim = dim;
-    h->ld = (dim + 3) & ~3;
+    // L2 rows carry -|x|^2 / 2 in an extra column (the query a 1.0), so that the inner product of the padded
+    // vectors ranks rows by distance; their stride is a multiple of 32 floats, which keeps the matrix-core path
+    h->ld = metric == RAG_METRIC_L2 ? (dim + 1 + 31) & ~31 : (dim + 3) & ~3;
     h->metric = metric;
     h->kind = kind;
     h->device = device;
@@ -415,7 +418,7 @@ static int add_common(rag_index_t* h, int64_t n, const float* x, bool x_on_devic
     DeviceGuard g(h->device);
     if (int rc = ws_acquire(h, h->stream)) return rc;
     if (int rc = ensure_rows(h, n)) return rc;
-    const int normalize = h->metric == RAG_METRIC_COSINE;
+    const int normalize = h->metric == RAG_METRIC_COSINE ? 1 : h->metric == RAG_METRIC_L2 ? 2 : 0;      // ingest mode
     float* dst = h->X + (size_t)h->n * h->ld;
     if (x_on_device) {
         if (!normalize && h->ld == h->dim) {
@@ -451,6 +454,7 @@ int rag_index_adopt_device(rag_index_t* h, int64_t n, float* x_dev) {
     if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
     if (h->n != 0 || h->X) return fail(RAG_ERR_INVALID, "adopt needs an empty index");
     if (h->kind != RAG_KIND_FLAT) return fail(RAG_ERR_UNSUPPORTED, "adopt is for FLAT indexes");
+    if (h->metric == RAG_METRIC_L2) return fail(RAG_ERR_UNSUPPORTED, "an L2 index stores an extra column per row: add the rows instead");
     if (n < 0 || (n > 0 && !x_dev)) return fail(RAG_ERR_INVALID, "bad buffer");
     if (h->dim % 4 != 0) return fail(RAG_ERR_INVALID, "adopt needs dim % 4 == 0");
     if ((reinterpret_cast<uintptr_t>(x_dev) & 15) != 0) return fail(RAG_ERR_INVALID, "adopt needs a 16-byte aligned buffer");
@@ -495,6 +499,7 @@ int rag_index_set_prefilter(rag_index_t* h, int mode) {
     if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
     if (mode != 0 && mode != 1) return fail(RAG_ERR_INVALID, "prefilter mode must be 0 (off) or 1 (bf16 first pass)");
     if (mode == 1 && h->kind != RAG_KIND_FLAT) return fail(RAG_ERR_UNSUPPORTED, "the bf16 first pass needs a FLAT index");
+    if (mode == 1 && h->metric == RAG_METRIC_L2) return fail(RAG_ERR_UNSUPPORTED, "the bf16 first pass is not available with the L2 metric");
     RAG_LOCK_INDEX(h);
     DeviceGuard g(h->device);
     if (mode == 0 && h->Xb) {
@@ -597,6 +602,8 @@ static int search_device_ordered(rag_index* h, int64_t nq, const float* q_dev, i
     if (h->n == 0) {
         hipLaunchKernelGGL(fill_results_kernel, dim3(grid_for(nq * k)), dim3(256), 0, s, D_dev, I, (long long)nq * k);
         RAG_HIP_CHECK(hipGetLastError());
+        if (h->metric == RAG_METRIC_L2)      // the same empty slots in the convention of distances: (-1, FLT_MAX)
+            RAG_HIP_CHECK(launch_l2_finish(q_dev, h->X, nq, 0, 0, k, 0, 0.f, nullptr, 0, D_dev, I, s));
         h->last_path = "empty";
         return RAG_OK;
     }
@@ -626,9 +633,25 @@ static int search_device_ordered(rag_index* h, int64_t nq, const float* q_dev, i
     if (h->metric == RAG_METRIC_IP && h->ld == h->dim && (reinterpret_cast<uintptr_t>(q_dev) & 15) == 0)
         qbuf = q_dev;
     else
-        RAG_HIP_CHECK(launch_prep_queries(q_dev, nq, h->dim, h->ld, 0 + (h->metric == RAG_METRIC_COSINE), static_cast<float*>(h->ws.ptr), s));
+        RAG_HIP_CHECK(launch_prep_queries(q_dev, nq, h->dim, h->ld, h->metric == RAG_METRIC_COSINE ? 1 : h->metric == RAG_METRIC_L2 ? 2 : 0,
+                                          static_cast<float*>(h->ws.ptr), s));
     if (h->kind == RAG_KIND_IVF)
         return ivf_search_device(h, nq, qbuf, k, min_score, nprobe, h->active, row_mask_dev, D_dev, I, s);
+    if (h->metric == RAG_METRIC_L2) {
+        // the k nearest rows are the k best under q.x - |x|^2 / 2.  That search leaves row positions (the id table and
+        // base are set aside for it; the index is locked and they are read when a launch is built, not later); the
+        // finishing kernel computes the distances themselves, applies the limit -- a distance -- and names the ids
+        long long* const ids = h->ids_dev;
+        const long long base = h->id_base;
+        h->ids_dev = nullptr;
+        h->id_base = 0;
+        const int rc = flat_search_prepared(h, nq, qbuf, k, -FLT_MAX, mask, D_dev, I, s);
+        h->ids_dev = ids;
+        h->id_base = base;
+        if (rc) return rc;
+        RAG_HIP_CHECK(launch_l2_finish(qbuf, h->X, nq, h->dim, h->ld, k, min_score >= 0.f, min_score, ids, base, D_dev, I, s));
+        return RAG_OK;
+    }
     return flat_search_prepared(h, nq, qbuf, k, min_score, mask, D_dev, I, s);
 }
 
@@ -681,6 +704,7 @@ static int segments_check(rag_index_t* h, int64_t nq, const float* q, int64_t ns
                           const int64_t* seg_end, int k, long long* rows_total) {
     if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
     if (h->kind != RAG_KIND_FLAT) return fail(RAG_ERR_UNSUPPORTED, "segment search needs a FLAT index");
+    if (h->metric == RAG_METRIC_L2) return fail(RAG_ERR_UNSUPPORTED, "segment search ranks by similarity: not available with the L2 metric");
     if (nq < 0 || nseg < 0) return fail(RAG_ERR_INVALID, "nq / nseg < 0");
     if (k < 1 || k > 1024) return fail(RAG_ERR_INVALID, "k must be in [1, 1024]");
     if (nq == 0 || nseg == 0) return RAG_OK;

@@ -23,8 +23,11 @@
 // of an IVF index, or caller-given row ranges (one block per range slice,
 // blockIdx.y = query).  Rows may also be the bf16 copy of the corpus (B16): same
 // kernel, half the bytes, fp32 query and accumulation.
+#include <float.h>
+
 #include "topk_keys.h"
 #include "kernels.h"
+#include "sort_entries.h"
 
 namespace rag {
 
@@ -586,7 +589,8 @@ __global__ void lists_to_keys_kernel(int nlists, long long nq, int k, const floa
     }
 }
 
-// queries -> padded (ld) and, for COSINE, normalised copies
+// queries -> padded (ld) copies; mode 1 (COSINE): normalised; mode 2 (L2): column d holds 1.0, which
+// meets the rows' -|x|^2 / 2 there, so the inner product of the padded vectors is q.x - |x|^2 / 2
 __global__ void prep_queries_kernel(const float* q, int d, int ld, int normalize, float* out) {
     const long long qi = blockIdx.x;
     const float* src = q + qi * d;
@@ -600,11 +604,65 @@ __global__ void prep_queries_kernel(const float* q, int d, int ld, int normalize
     float tot = 0.f;
     for (int i = 0; i < (int)(blockDim.x >> 6); ++i) tot += s_part[i];
     float inv = 1.f;
-    if (normalize) { const float nrm = sqrtf(tot); inv = nrm > 0.f ? 1.f / nrm : 1.f; }
-    for (int i = threadIdx.x; i < ld; i += blockDim.x) dst[i] = (i < d) ? src[i] * inv : 0.f;
+    if (normalize == 1) { const float nrm = sqrtf(tot); inv = nrm > 0.f ? 1.f / nrm : 1.f; }
+    for (int i = threadIdx.x; i < ld; i += blockDim.x) dst[i] = (i < d) ? src[i] * inv : (normalize == 2 && i == d) ? 1.f : 0.f;
 }
 
-// rows: copy n x d -> n x ld (zero padded), optionally normalised (one wave per row)
+// L2 index: the search ranked the rows by q.x - |x|^2 / 2 and left the ROW POSITIONS of the k best in I.
+// Here every kept row gets its squared distance as FAISS's and Qdrant's scans compute it -- the sum of
+// the squared fp32 differences (q - x)_i, accumulated in fp64 and rounded once, so a row equal to the
+// query is at distance exactly 0 -- the list is sorted by (distance, row position), rows farther than
+// max_d2 are dropped when a limit is given, and positions become ids.  Empty slots: (-1, FLT_MAX).
+// One workgroup per query; a wave per candidate row.
+__global__ __launch_bounds__(256) void l2_finish_kernel(const float* qbuf, const float* X, int d, int ld, int k, int use_limit,
+                                                        float max_d2, const long long* row_ids, long long id_base, float* D,
+                                                        long long* I) {
+    __shared__ SortEntry e[1024];
+    const long long qi = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* q = qbuf + qi * ld;
+    int P = 64;
+    while (P < k) P <<= 1;
+    for (int j = wave; j < P; j += 4) {
+        const long long pos = j < k ? I[(size_t)qi * k + j] : -1;      // wave-uniform
+        double ss = 0.0;
+        if (pos >= 0) {
+            const float* x = X + pos * (long long)ld;
+            for (int i = lane; i < d; i += 64) {
+                const float f = q[i] - x[i];
+                ss = fma((double)f, (double)f, ss);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+        }
+        if (lane == 0) {
+            const float dist = (float)ss;
+            SortEntry t;
+            t.key = pos >= 0 ? f64_ordered(-(double)dist) : 0ull;       // nearest first; empty slots last
+            t.idx = pos >= 0 ? (uint32_t)pos : 0xFFFFFFFFu;
+            t.pad = __float_as_uint(dist);
+            e[j] = t;
+        }
+    }
+    sort_entries(e, P, tid, 256);
+    for (int j = tid; j < k; j += 256) {
+        const SortEntry t = e[j];
+        float dist = FLT_MAX;
+        long long id = -1;
+        if (t.idx != 0xFFFFFFFFu) {
+            const float v = __uint_as_float(t.pad);
+            if (!use_limit || v <= max_d2) {
+                dist = v;
+                id = row_ids ? row_ids[t.idx] : id_base + (long long)t.idx;
+            }
+        }
+        D[(size_t)qi * k + j] = dist;
+        I[(size_t)qi * k + j] = id;
+    }
+}
+
+// rows: copy n x d -> n x ld (zero padded); mode 1: normalised; mode 2 (L2): column d = -|x|^2 / 2,
+// the norm summed in fp64 (one wave per row)
 __global__ void ingest_rows_kernel(const float* src, long long n, int d, int ld, int normalize, float* dst) {
     const int lane = threadIdx.x & 63;
     const long long wave = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
@@ -614,14 +672,21 @@ __global__ void ingest_rows_kernel(const float* src, long long n, int d, int ld,
         float ss = 0.f;
         for (int i = lane; i < d; i += 64) { const float v = s[i]; ss += v * v; }
         float inv = 1.f;
-        if (normalize) {
+        float aug = 0.f;
+        if (normalize == 2) {
+            double sd = 0.0;
+            for (int i = lane; i < d; i += 64) sd = fma((double)s[i], (double)s[i], sd);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) sd += __shfl_xor(sd, off, 64);
+            aug = (float)(-0.5 * sd);
+        } else if (normalize) {
             ss = wave_sum_to_lane63(ss);
             const float tot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ss), 63));
             const float nrm = sqrtf(tot);
             inv = nrm > 0.f ? 1.f / nrm : 1.f;
         }
         float* o = dst + r * ld;
-        for (int i = lane; i < ld; i += 64) o[i] = (i < d) ? s[i] * inv : 0.f;
+        for (int i = lane; i < ld; i += 64) o[i] = (i < d) ? s[i] * inv : (i == d) ? aug : 0.f;
     }
 }
 
@@ -745,6 +810,12 @@ hipError_t launch_lists_to_keys(int nlists, long long nq, int k, const float* D,
 
 hipError_t launch_prep_queries(const float* q, long long nq, int d, int ld, int normalize, float* out, hipStream_t s) {
     hipLaunchKernelGGL(prep_queries_kernel, dim3((unsigned)nq), dim3(256), 0, s, q, d, ld, normalize, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_l2_finish(const float* qbuf, const float* X, long long nq, int d, int ld, int k, int use_limit, float max_d2,
+                            const long long* row_ids, long long id_base, float* D, long long* I, hipStream_t s) {
+    hipLaunchKernelGGL(l2_finish_kernel, dim3((unsigned)nq), dim3(256), 0, s, qbuf, X, d, ld, k, use_limit, max_d2, row_ids, id_base, D, I);
     return hipGetLastError();
 }
 

@@ -1029,6 +1029,7 @@ static int hybrid_check(rag_index* h, int topn, int64_t nb, int fuse_limit, int 
                         const rag_hybrid_out_t* out) {
     if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
     if (!out || !out->ids || !out->scores || !out->n_out) return fail(RAG_ERR_INVALID, "out->ids / scores / n_out are required");
+    if (h->metric == RAG_METRIC_L2) return fail(RAG_ERR_UNSUPPORTED, "the fusion divides similarities by their maximum: not available with the L2 metric");
     if (topn < 1 || topn > HYB_MAX_SEM) return fail(RAG_ERR_INVALID, "topn must be in [1, " + std::to_string(HYB_MAX_SEM) + "]");
     if (nb < 0 || nb > HYB_MAX_BM) return fail(RAG_ERR_INVALID, "at most " + std::to_string(HYB_MAX_BM) + " keyword hits");
     if (fuse_limit < 1 || fuse_limit > MMR_SIM_MAX_N) return fail(RAG_ERR_INVALID, "fuse_limit must be in [1, " + std::to_string(MMR_SIM_MAX_N) + "]");

@@ -64,6 +64,8 @@ hipError_t launch_lists_to_keys(int nlists, long long nq, int k, const float* D,
                                 long long i_stride, u64* keys, hipStream_t s);
 hipError_t launch_prep_queries(const float* q, long long nq, int d, int ld, int normalize, float* out, hipStream_t s);
 hipError_t launch_ingest_rows(const float* src, long long n, int d, int ld, int normalize, float* dst, hipStream_t s);
+hipError_t launch_l2_finish(const float* qbuf, const float* X, long long nq, int d, int ld, int k, int use_limit, float max_d2,
+                            const long long* row_ids, long long id_base, float* D, long long* I, hipStream_t s);
 hipError_t launch_gather_rows(const float* X, int d, int ld, long long n, const long long* rows, long long ntotal, float* out, hipStream_t s);
 
 }  // namespace rag

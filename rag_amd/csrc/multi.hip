@@ -137,6 +137,7 @@ int rag_multi_create(int dim, int metric, int kind, int n_devices, const int* de
     *out = nullptr;
     if (n_devices < 1 || n_devices > 64) return fail(RAG_ERR_INVALID, "n_devices must be in [1, 64]");
     if (!device_ids) return fail(RAG_ERR_INVALID, "device_ids is NULL");
+    if (metric == RAG_METRIC_L2) return fail(RAG_ERR_UNSUPPORTED, "the per-device answers are merged best similarity first: not available with the L2 metric");
     std::unique_ptr<rag_multi> h(new rag_multi());
     h->dim = dim;
     h->kind = kind;

@@ -123,10 +123,12 @@ extern "C" int rag_index_load(const char* path, int device, rag_index_t** out) {
     const bool ivf = (hd.flags & 4) != 0;
     if (hd.n < 0 || hd.dim < 1 || (hd.flags & ~7) != 0 || (ivf ? hd.nlist < 1 : hd.nlist != 0))
         return fail(RAG_ERR_INVALID, "corrupt snapshot header");
-    if (hd.metric != RAG_METRIC_IP && hd.metric != RAG_METRIC_COSINE) return fail(RAG_ERR_INVALID, "snapshot names an unknown metric");
+    if (hd.metric != RAG_METRIC_IP && hd.metric != RAG_METRIC_COSINE && hd.metric != RAG_METRIC_L2) return fail(RAG_ERR_INVALID, "snapshot names an unknown metric");
+    if (hd.metric == RAG_METRIC_L2 && ivf) return fail(RAG_ERR_INVALID, "corrupt snapshot header");
     rag_index* h = nullptr;
     // rows in the file are already normalised for COSINE: load them as they are, then restore the metric
-    if (int rc = rag_index_create(hd.dim, RAG_METRIC_IP, ivf ? RAG_KIND_IVF : RAG_KIND_FLAT, device, &h)) return rc;
+    // (L2 rows are stored as given; adding them rebuilds their extra column)
+    if (int rc = rag_index_create(hd.dim, hd.metric == RAG_METRIC_L2 ? RAG_METRIC_L2 : RAG_METRIC_IP, ivf ? RAG_KIND_IVF : RAG_KIND_FLAT, device, &h)) return rc;
     struct Guard { rag_index* h; bool keep; ~Guard() { if (!keep) rag_index_free(h); } } guard{h, false};
     if (int rc = rag_index_set_id_base(h, hd.id_base)) return rc;
     const long long chunk = std::max<long long>(1, (64LL << 20) / ((long long)hd.dim * 4));

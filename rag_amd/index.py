@@ -30,10 +30,15 @@ def _ptr(a: Optional[np.ndarray]):
 
 
 class DeviceIndex:
-    """metric: 'ip' | 'cosine'; kind: 'flat' | 'ivf'."""
+    """metric: 'ip' | 'cosine' | 'l2'; kind: 'flat' | 'ivf'.
+
+    An 'l2' index (flat only) answers with SQUARED distances, smallest first, empty slots as
+    ``(-1, FLT_MAX)``; its ``min_score`` argument is the largest squared distance to return (None or a
+    negative value: no limit).  Segment search, the fusion pipeline and the several-GPU indexes rank by
+    similarity and refuse it."""
 
     def __init__(self, dim: int, metric: str = "cosine", kind: str = "flat", device: int = 0):
-        metrics = {"ip": _lib.METRIC_IP, "dot": _lib.METRIC_IP, "cosine": _lib.METRIC_COSINE}
+        metrics = {"ip": _lib.METRIC_IP, "dot": _lib.METRIC_IP, "cosine": _lib.METRIC_COSINE, "l2": _lib.METRIC_L2}
         kinds = {"flat": _lib.KIND_FLAT, "ivf": _lib.KIND_IVF}
         if metric not in metrics:
             raise ValueError(f"unknown metric {metric!r}")
@@ -85,7 +90,7 @@ class DeviceIndex:
         self.dim = int(lib.rag_index_dim(h))
         self.device = int(device)
         self.kind = "ivf" if int(lib.rag_index_kind(h)) == _lib.KIND_IVF else "flat"
-        self.metric = "cosine" if int(lib.rag_index_metric(h)) == _lib.METRIC_COSINE else "ip"
+        self.metric = {_lib.METRIC_COSINE: "cosine", _lib.METRIC_L2: "l2"}.get(int(lib.rag_index_metric(h)), "ip")
         return self
 
     # --------------------------------------------------------------- measurement
@@ -310,7 +315,7 @@ class MultiDeviceIndex:
     ``devices`` may name a GPU more than once.  numpy in, numpy out, like ``DeviceIndex.search``."""
 
     def __init__(self, dim: int, devices: Sequence[int], metric: str = "ip", kind: str = "flat"):
-        metrics = {"ip": _lib.METRIC_IP, "dot": _lib.METRIC_IP, "cosine": _lib.METRIC_COSINE}
+        metrics = {"ip": _lib.METRIC_IP, "dot": _lib.METRIC_IP, "cosine": _lib.METRIC_COSINE, "l2": _lib.METRIC_L2}   # 'l2': refused by the library
         kinds = {"flat": _lib.KIND_FLAT, "ivf": _lib.KIND_IVF}
         if metric not in metrics or kind not in kinds:
             raise ValueError(f"unknown metric {metric!r} or index kind {kind!r}")

@@ -24,7 +24,7 @@ from .filters import payload_passes
 from .index import DeviceIndex
 from .schemas import Chunk, IndexType, MetricType, SearchConfig, SearchError, device_limit
 
-_METRIC = {MetricType.COSINE: "cosine", MetricType.DOT_PRODUCT: "ip"}
+_METRIC = {MetricType.COSINE: "cosine", MetricType.DOT_PRODUCT: "ip", MetricType.EUCLIDEAN: "l2"}
 
 
 class HipSearchOptimizer:
@@ -37,8 +37,10 @@ class HipSearchOptimizer:
         self.collection_name = config.collection_name
         self.logger = logging.getLogger(__name__)
         kind = "ivf" if config.index_type == IndexType.IVF else "flat"
+        if config.metric == MetricType.EUCLIDEAN and kind != "flat":
+            raise SearchError("the euclidean metric needs a flat index on the HIP backend")
         self.index = DeviceIndex(config.dimension, metric=_METRIC[config.metric], kind=kind, device=config.device)
-        if config.quantization_config is not None and kind == "flat":
+        if config.quantization_config is not None and kind == "flat" and config.metric != MetricType.EUCLIDEAN:
             self.index.set_prefilter(True)
         self.payloads: List[Dict[str, Any]] = []       # row position -> payload
         self.point_ids: List[Any] = []                 # row position -> point id given at upsert
@@ -141,8 +143,17 @@ class HipSearchOptimizer:
             if limit < 1:
                 return [[] for _ in range(q.shape[0])]
             nprobe = (search_params or {}).get("nprobe", self.config.nprobe)
-            D, I = self.index.search(q, device_limit(limit), min_score=min_score, nprobe=nprobe,
-                                     row_mask=self._mask(filters))
+            if self.config.metric == MetricType.EUCLIDEAN:
+                # Distance.EUCLID (search_optimizer.py:104-105): the score is the distance, smallest first, and
+                # `score_threshold` (:217, fed with min_score) is the LARGEST distance returned
+                if min_score is not None and min_score < 0:
+                    return [[] for _ in range(q.shape[0])]
+                D, I = self.index.search(q, device_limit(limit), min_score=None if min_score is None else float(min_score) ** 2,
+                                         row_mask=self._mask(filters))
+                D = np.sqrt(np.where(I >= 0, D, 0.0))
+            else:
+                D, I = self.index.search(q, device_limit(limit), min_score=min_score, nprobe=nprobe,
+                                         row_mask=self._mask(filters))
             return [self._to_chunks(D[i], I[i]) for i in range(q.shape[0])]
         except Exception as e:
             self.logger.error(f"Search operation failed: {e}")

@@ -50,6 +50,8 @@ class ShardedIndex:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if getattr(local_index, "metric", None) == "l2":
+            raise ValueError("the exchange merges best similarity first: an 'l2' index cannot be sharded")
         self.index = local_index
         self.row_base = int(row_base)        # global position of the local index's first row (hybrid_mmr)
         if local_search is None:

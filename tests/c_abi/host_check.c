@@ -183,6 +183,23 @@ int main(void) {
     CHECK(rag_similarity_matrix(2, d, back, 0, 7, 0, S2) == RAG_ERR_INVALID, "unknown similarity metric accepted");
     CHECK(rag_index_free(h) == RAG_OK, "free");
 
+    /* L2 metric: squared distances, nearest first; a stored row is at distance 0 from itself; the threshold argument is
+       the largest squared distance returned */
+    rag_index_t* l2 = NULL;
+    CHECK(rag_index_create(d, RAG_METRIC_L2, RAG_KIND_FLAT, 0, &l2) == RAG_OK, "create l2");
+    CHECK(rag_index_add(l2, 5000, X, NULL) == RAG_OK, "add l2");
+    float D2[4];
+    int64_t I2[4];
+    CHECK(rag_index_search(l2, 1, X + (size_t)77 * d, 4, -1.0f, 1, NULL, D2, I2) == RAG_OK, "search l2");
+    CHECK(I2[0] == 77 && D2[0] == 0.0f && D2[1] > 0.0f && D2[1] <= D2[2] && D2[2] <= D2[3], "l2 order %lld %g %g", (long long)I2[0], D2[0], D2[1]);
+    double want = 0.0;
+    for (int j = 0; j < d; ++j) { const double f = (double)X[(size_t)77 * d + j] - (double)X[(size_t)I2[1] * d + j]; want += f * f; }
+    CHECK(fabs(D2[1] - want) <= 1e-5 * want + 1e-6, "l2 distance %g vs %g", D2[1], want);
+    CHECK(rag_index_search(l2, 1, X + (size_t)77 * d, 4, 0.0f, 1, NULL, D2, I2) == RAG_OK, "search l2 limit");
+    CHECK(I2[0] == 77 && I2[1] == -1 && D2[1] == FLT_MAX, "l2 limit 0 keeps %lld %lld", (long long)I2[0], (long long)I2[1]);
+    CHECK(rag_index_create(d, RAG_METRIC_L2, RAG_KIND_IVF, 0, &h) == RAG_ERR_UNSUPPORTED, "l2 ivf accepted");
+    CHECK(rag_index_free(l2) == RAG_OK, "free l2");
+
     /* IVF: every list probed = the exhaustive answer */
     const int nlist = 16;
     CHECK(rag_index_create(d, RAG_METRIC_IP, RAG_KIND_IVF, 0, &h) == RAG_OK, "create ivf");

@@ -176,3 +176,29 @@ def test_flat_ip_semantics():
     Ibad = I.copy()
     Ibad[0, 0] = 4999 if I[0, 0] != 4999 else 4998
     assert flat.compare_topk(D, Ibad, D, I) != []
+
+
+def test_flat_l2_semantics():
+    """flat_l2_search against sums of squared differences: ascending squared distances, lower id first
+    among equal ones, (-1, FLT_MAX) padding, limit, mask and ids.  Parity unpinned (no FAISS / Qdrant here)."""
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((400, 12)).astype(np.float32)
+    Q = rng.standard_normal((4, 12)).astype(np.float32)
+    X[300] = X[20]
+    Q[0] = X[20]
+    ref = ((Q[:, None, :].astype(np.float64) - X[None].astype(np.float64)) ** 2).sum(-1)
+    order = np.argsort(ref, axis=1, kind="stable")
+    D, I = flat.flat_l2_search(X, Q, 7)
+    assert np.array_equal(I, order[:, :7]) and np.allclose(D, np.take_along_axis(ref, order[:, :7], 1), rtol=1e-6, atol=1e-6)
+    assert I[0, 0] == 20 and I[0, 1] == 300 and D[0, 0] == 0.0 and D[0, 1] == 0.0
+    lim = float(D[1, 3])
+    D2, I2 = flat.flat_l2_search(X, Q[1:2], 7, max_dist2=lim)
+    assert I2[0, :4].tolist() == I[1, :4].tolist() and np.all(I2[0, 4:] == -1) and np.all(D2[0, 4:] == flat.FLT_MAX)
+    mask = np.ones(400, np.uint8)
+    mask[order[2, 0]] = 0
+    ids = np.arange(400, dtype=np.int64) * 3 + 1
+    D3, I3 = flat.flat_l2_search(X, Q[2:3], 3, row_mask=mask, ids=ids)
+    assert I3[0].tolist() == (order[2, 1:4] * 3 + 1).tolist()
+    D4, I4 = flat.flat_l2_search(X[:2], Q, 5)
+    assert np.all(I4[:, 2:] == -1) and np.all(D4[:, 2:] == flat.FLT_MAX)
+    assert flat.compare_topk_l2(D, I, D, I) == [] and flat.compare_topk_l2(D, I, D + 1.0, I) != []
