@@ -813,9 +813,13 @@ static GemmPlan gemm_plan(const rag_index* h, long long nq, int k) {
     p.nqb_pad = p.nqb > 8 ? ((p.nqb + 7) & ~7) : p.nqb;
     long long s = target_wgs / p.nqb_pad;
     if (s < 1) s = 1;
-    // a row range should hold at least 8 tiles, or splitting costs more than it spreads
+    // a row range should hold at least 8 tiles, or splitting costs more than it spreads -- unless the grid would
+    // then leave compute units without a workgroup (a short corpus under a large batch: the 16384 centroids of an
+    // IVF index under 4096 queries are 64 tiles for 16 query blocks), where ranges go down to one tile
+    static const int min_tiles_short = std::max(1, env_int_g("RAG_GEMM_MIN_TILES_SHORT", 1));      // measurement knob
     p.ntiles = (h->n + p.RT - 1) / p.RT;
-    const long long max_s = (p.ntiles + 7) / 8;
+    long long max_s = (p.ntiles + 7) / 8;
+    if (max_s * p.nqb_pad < target_wgs) max_s = std::max(max_s, (p.ntiles + min_tiles_short - 1) / min_tiles_short);
     if (s > max_s) s = max_s < 1 ? 1 : max_s;
     p.S = (int)s;
     // placement over the XCDs: the widest split of the query blocks that the counts allow
