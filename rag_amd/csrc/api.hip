@@ -170,6 +170,10 @@ size_t ivf_search_workspace(const rag_index* h, long long nq, int k, int nprobe)
 int gemm_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask,
                      float* D, long long* I, hipStream_t s);                 // gemm_topk.hip
 bool gemm_topk_supported(const rag_index* h, long long nq, int k);
+bool gemm_scores_supported(const rag_index* h, long long nq, int k);
+size_t gemm_scores_workspace(const rag_index* h, long long nq);
+int gemm_scores_search(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask, float* D,
+                       long long* I, hipStream_t s);
 bool prefilter_scan_supported(const rag_index* h, long long nq, int k);       // gemm_topk.hip
 size_t prefilter_scan_workspace(const rag_index* h, int k);
 int prefilter_scan_search(rag_index* h, const float* qbuf, int k, float min_score, const uint8_t* mask,
@@ -292,6 +296,7 @@ static bool use_direct(const rag_index* h, long long nq, int k) { return !h->pre
 
 size_t flat_search_workspace(const rag_index* h, long long nq, int k) {
     if (use_direct(h, nq, k)) return direct_topk_workspace(h, nq);
+    if (gemm_scores_supported(h, nq, k)) return gemm_scores_workspace(h, nq);
     if (use_narrow(h, nq, k)) return narrow_topk_workspace(h, nq, k);
     if (gemm_topk_supported(h, nq, k)) return gemm_topk_workspace(h, nq, k);
     if (prefilter_scan_supported(h, nq, k)) return prefilter_scan_workspace(h, k);
@@ -307,6 +312,7 @@ int flat_search_prepared(rag_index* h, long long nq, const float* qbuf, int k, f
     if (int rc = h->ws.ensure(qbytes + flat_search_workspace(h, nq, k))) return rc;
     if (use_direct(h, nq, k))
         return direct_topk_search(h, nq, qbuf, k, min_score, mask, D, I, reinterpret_cast<float*>(static_cast<char*>(h->ws.ptr) + qbytes), s);
+    if (gemm_scores_supported(h, nq, k)) return gemm_scores_search(h, nq, qbuf, k, min_score, mask, D, I, s);
     if (use_narrow(h, nq, k)) return narrow_topk_search(h, nq, qbuf, k, min_score, mask, D, I, s);
     if (gemm_topk_supported(h, nq, k)) return gemm_topk_search(h, nq, qbuf, k, min_score, mask, D, I, s);
     if (prefilter_scan_supported(h, nq, k)) return prefilter_scan_search(h, qbuf, k, min_score, mask, D, I, s);

@@ -244,6 +244,9 @@ __global__ __launch_bounds__(1024) void direct_select_kernel(SelectArgs p) {
     }
 }
 
+int direct_select_launch(rag_index* h, long long nq, int k, float min_score, const uint8_t* mask, const float* scores, float* D,
+                         long long* I, hipStream_t s);
+
 bool direct_topk_supported(const rag_index* h, long long nq, int k) {
     static const int on = getenv("RAG_DIRECT_TOPK") ? atoi(getenv("RAG_DIRECT_TOPK")) : 1;          // measurement knob
     return on && h->kind == RAG_KIND_FLAT && nq >= 1 && nq <= 4 && h->n >= 1024 && h->n <= SEL_REG_MAX * 1024 &&
@@ -267,6 +270,15 @@ int direct_topk_search(rag_index* h, long long nq, const float* qbuf, int k, flo
     else hipLaunchKernelGGL(direct_scores_kernel<4>, dim3(blocks), dim3(256), lds, s, h->X, n, h->ld, qbuf, scores);
     RAG_HIP_CHECK(hipGetLastError());
     if (int rc = profile_end(h, s)) return rc;
+    if (int rc = direct_select_launch(h, nq, k, min_score, mask, scores, D, I, s)) return rc;
+    h->last_path = "direct";
+    return RAG_OK;
+}
+
+// the k best of every query's n scores ([nq][n], n <= 32768): one selection workgroup per query
+int direct_select_launch(rag_index* h, long long nq, int k, float min_score, const uint8_t* mask, const float* scores, float* D,
+                         long long* I, hipStream_t s) {
+    const int n = (int)h->n;
     SelectArgs p = {};
     p.scores = scores;
     p.n = n;
@@ -282,7 +294,6 @@ int direct_topk_search(rag_index* h, long long nq, const float* qbuf, int k, flo
     else if (n <= 16 * 1024) hipLaunchKernelGGL(direct_select_kernel<16>, dim3((unsigned)nq), dim3(1024), 0, s, p);
     else hipLaunchKernelGGL(direct_select_kernel<SEL_REG_MAX>, dim3((unsigned)nq), dim3(1024), 0, s, p);
     RAG_HIP_CHECK(hipGetLastError());
-    h->last_path = "direct";
     return RAG_OK;
 }
 

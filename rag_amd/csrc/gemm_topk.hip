@@ -137,6 +137,8 @@ struct GemmArgs {
     // k-th best approximate score minus the margin, below which no range needs to keep a row (and
     // which also lies below the exact k-th best, so the fp32 fallback may start from it).
     unsigned int* gthr;
+    // STORE variant: every score goes to scores[query * n + row] and nothing is selected
+    float* scores;
 };
 
 // cache policy bits of the corpus loads in the narrow shapes (2 = non-temporal)
@@ -279,9 +281,10 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f16v (&acc)[2][
 
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 
-template <int RT, int QT, int NW, bool B16, bool TASKS = false>
+template <int RT, int QT, int NW, bool B16, bool TASKS = false, bool STORE = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(GemmArgs a) {
     static_assert(!TASKS || (!B16 && QT == 32), "work items of the list-major scan use the 256 x 32 fp32 shape");
+    static_assert(!STORE || (!B16 && !TASKS), "the score-writing variant is the plain fp32 kernel without its selection");
     constexpr int NT = NW * 64;              // threads
     constexpr int WM = RT / 64;              // waves along the corpus rows
     constexpr int WQ = NW / WM;              // waves along the queries
@@ -564,12 +567,36 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
             if (keep == 123.456f) s_thr[0] = keep;      // keeps the accumulators live
             continue;
         }
+        if constexpr (STORE) {
+            // a lane holds, per query column, runs of 4 consecutive rows: one 16-byte store each where the row count allows
+            const long long rbase = row_lo + t * RT + wm * 64;
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj) {
+                const int ql = wq * NJ * 32 + nj * 32 + l31;
+                if (ql >= m_valid) continue;
+                float* out = a.scores + (size_t)(q0 + ql) * (size_t)a.n;
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const long long row = rbase + mi * 32 + 8 * g + 4 * h;
+                        if ((a.n & 3) == 0 && row + 3 < row_hi) {
+                            *reinterpret_cast<f4*>(out + row) = (f4){acc[mi][nj][4 * g], acc[mi][nj][4 * g + 1], acc[mi][nj][4 * g + 2], acc[mi][nj][4 * g + 3]};
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (row + e < row_hi) out[row + e] = acc[mi][nj][4 * g + e];
+                        }
+                    }
+            }
+            continue;
+        }
         tile_epilogue<RT, QT, NJ>(a, acc, cand, s_thr, s_cnt, s_flag, m_valid, row_lo + t * RT + wm * 64, row_hi, wq * NJ * 32, l31, h, tg);
     }
 
     // ---- final: every query's k best keys of this row range -> part ---------------------
     __syncthreads();
-    {
+    if constexpr (!STORE) {
         u64* scratch = reinterpret_cast<u64*>(As) + wave * CAPQ2;
         for (int ql = wave; ql < QT; ql += NW) {
             if (ql >= m_valid) continue;
@@ -1000,6 +1027,81 @@ int gemm_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float
     if (int rc2 = profile_end(h, s)) return rc2;
     RAG_HIP_CHECK(launch_merge_keys(m, nq, s));
     h->last_path = "gemm";
+    return RAG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// A large batch over a short corpus (the coarse step of an IVF search: 16384 centroids under 4096
+// queries, top-64): a workgroup's row range is a few tiles, far too few rows for a threshold to
+// build up, so the in-kernel selection pushes a large share of every tile (2.1 ms for 0.87 ms of
+// arithmetic at that shape).  Here the matrix-core kernel writes every score (nq x n fp32: 268 MB at
+// that shape, a few tens of microseconds of HBM traffic) and one workgroup per query selects its k
+// best with the selection kernel of the few-query path (direct_topk.hip).  Same MFMA chain per
+// (row, query) as every other shape, same order rule.
+int direct_select_launch(rag_index* h, long long nq, int k, float min_score, const uint8_t* mask, const float* scores, float* D,
+                         long long* I, hipStream_t s);      // direct_topk.hip
+constexpr long long SCORES_MAX_ROWS = 32768;                 // what one selection workgroup holds in registers
+
+// the shape alone (an IVF index asks this of its quantizer, whose bf16 first pass serves the assignment of new rows only)
+bool gemm_scores_shape_ok(const rag_index* h, long long nq, int k) {
+    static const int min_nq = env_int_g("RAG_GEMM_SCORES_MIN_NQ", 128);        // 0 switches the path off (measurement knob)
+    return min_nq > 0 && h->kind == RAG_KIND_FLAT && (h->ld % GK) == 0 && h->n >= 1024 && h->n <= SCORES_MAX_ROWS &&
+           nq >= min_nq && k >= 1 && k <= 1024 && (size_t)nq * (size_t)h->n * sizeof(float) <= ((size_t)2 << 30);
+}
+
+bool gemm_scores_supported(const rag_index* h, long long nq, int k) { return !h->prefilter && gemm_scores_shape_ok(h, nq, k); }
+
+size_t gemm_scores_workspace(const rag_index* h, long long nq) { return ((size_t)nq * (size_t)h->n * sizeof(float) + 255) & ~(size_t)255; }
+
+template <int RT, int QT, int NW>
+static int launch_gemm_store(const GemmArgs& a, int grid, int device, hipStream_t s) {
+    const size_t lds = (size_t)(2 * (RT + QT) * GK) * sizeof(float) + QT * 8 + 16;
+    static bool attr_set[64] = {};
+    if (!attr_set[device & 63]) {
+        RAG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_topk_kernel<RT, QT, NW, false, false, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[device & 63] = true;
+    }
+    hipLaunchKernelGGL((gemm_topk_kernel<RT, QT, NW, false, false, true>), dim3(grid), dim3(NW * 64), lds, s, a);
+    RAG_HIP_CHECK(hipGetLastError());
+    return RAG_OK;
+}
+
+int gemm_scores_search(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask, float* D,
+                       long long* I, hipStream_t s) {
+    GemmPlan p = gemm_plan(h, nq, k);
+    if (p.QT != 256) {                       // 128 .. 1023 queries: the 128 x 128 shape
+        p.QT = 128; p.RT = 128; p.NW = 4;
+        p.nqb = (int)((nq + 127) / 128);
+        p.nqb_pad = p.nqb > 8 ? ((p.nqb + 7) & ~7) : p.nqb;
+        p.ntiles = (h->n + 127) / 128;
+        p.S = (int)std::max<long long>(1, std::min<long long>(p.ntiles, (512 + p.nqb_pad - 1) / p.nqb_pad));
+        p.gq = 0;
+    }
+    const size_t qbytes = ((size_t)nq * h->ld * sizeof(float) + 255) & ~(size_t)255;
+    if (h->ws.bytes < qbytes + gemm_scores_workspace(h, nq)) return fail(RAG_ERR_INVALID, "internal: workspace not sized for the score matrix");
+    GemmArgs a = {};
+    a.X = h->X;
+    a.Q = qbuf;
+    a.n = h->n;
+    a.ntiles = p.ntiles;
+    a.nq = (int)nq;
+    a.ld = h->ld;
+    a.k = k;
+    a.nqb = p.nqb;
+    a.nqb_pad = p.nqb_pad;
+    a.S = p.S;
+    a.gq = p.gq;
+    a.outc = k;
+    a.trig = gemm_trig(p.RT, p.QT, k);
+    a.scores = reinterpret_cast<float*>(static_cast<char*>(h->ws.ptr) + qbytes);
+    const int grid = p.nqb_pad * p.S;
+    if (int rc = profile_begin(h, s)) return rc;
+    int rc = p.QT == 256 ? launch_gemm_store<256, 256, 8>(a, grid, h->device, s) : launch_gemm_store<128, 128, 4>(a, grid, h->device, s);
+    if (rc) return rc;
+    if (int rc2 = profile_end(h, s)) return rc2;
+    if (int rc3 = direct_select_launch(h, nq, k, min_score, mask, a.scores, D, I, s)) return rc3;
+    h->last_path = "gemm-scores";
     return RAG_OK;
 }
 

@@ -64,6 +64,10 @@ static long long ivf_slices(const rag_index* h, long long nq, int nprobe) {
     return slices < 1 ? 1 : slices;
 }
 
+bool gemm_scores_shape_ok(const rag_index* h, long long nq, int k);                          // gemm_topk.hip
+size_t gemm_scores_workspace(const rag_index* h, long long nq);
+int gemm_scores_search(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask, float* D,
+                       long long* I, hipStream_t s);
 bool ivf_listmajor_supported(const rag_index* h, long long nq, int k, int nprobe);            // gemm_topk.hip
 size_t ivf_listmajor_workspace(const rag_index* h, long long nq, int k, int nprobe);
 int ivf_listmajor_scan(rag_index* h, long long nq, const float* qbuf, int k, float min_score, int nprobe,
@@ -212,6 +216,12 @@ int ivf_search_device(rag_index* h, long long nq, const float* qbuf, int k, floa
     if (direct) {
         float* scores = reinterpret_cast<float*>(static_cast<char*>(v.ws.ptr) + cdb + cib + mb);
         if (int rc = direct_topk_search(v.quantizer, nq, qbuf, nprobe, -FLT_MAX, nullptr, cD, cI, scores, s)) return rc;
+    } else if (gemm_scores_shape_ok(v.quantizer, nq, nprobe)) {
+        // a large batch against a short centroid table: every (query, list) score written by the matrix-core kernel,
+        // then one selection workgroup per query
+        const size_t cq = ((size_t)nq * v.quantizer->ld * sizeof(float) + 255) & ~(size_t)255;
+        if (int rc = v.quantizer->ws.ensure(cq + gemm_scores_workspace(v.quantizer, nq))) return rc;
+        if (int rc = gemm_scores_search(v.quantizer, nq, qbuf, nprobe, -FLT_MAX, nullptr, cD, cI, s)) return rc;
     } else if (int rc = flat_search_prepared(v.quantizer, nq, qbuf, nprobe, -FLT_MAX, nullptr, cD, cI, s)) {
         return rc;
     }

@@ -7,6 +7,8 @@ def flat_fp32_path(n, d, nq, k):
     ld = (d + 3) // 4 * 4
     if 1 <= nq <= 4 and 1024 <= n <= 32768 and 1 <= k <= 1024 and ld <= 3072:
         return "direct"
+    if nq >= 128 and 1024 <= n <= 32768 and 1 <= k <= 1024 and ld % 32 == 0 and nq * n * 4 <= 2 << 30:
+        return "gemm-scores"          # every score written by the matrix-core kernel, one selection workgroup per query
     if 5 <= nq <= 32 and k <= 32 and n >= 4096 and ld % 128 == 0:
         nj = 1 if nq <= 16 else 2
         if ld * nj * 64 + 8 * 4096 + 8 * nj * 16 * 8 + 48 <= 160 * 1024:

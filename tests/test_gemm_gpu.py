@@ -69,7 +69,7 @@ def test_gemm_adversarial_order_duplicates_and_mask(nq):
     assert idx.last_path == flat_fp32_path(n, d, nq, 10)
     _check(D, I, X, Q, 10)
     D, I = idx.search(Q, 64)
-    assert idx.last_path == "gemm"
+    assert idx.last_path == flat_fp32_path(n, d, nq, 64)
     _check(D, I, X, Q, 64)
     mask = (rng.uniform(size=n) < 0.2).astype(np.uint8)
     D, I = idx.search(Q, 10, row_mask=mask)
@@ -101,4 +101,40 @@ def test_batch_and_single_query_kernels_agree_bitwise_on_ids():
     Ds = np.concatenate([r[0] for r in rows])
     assert np.array_equal(Ig, Is)
     assert np.allclose(Dg, Ds, rtol=RTOL, atol=ATOL)
+    idx.close()
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(1024, 64, 128, 10), (32_768, 128, 300, 64), (16_384, 1024, 1100, 64), (9_001, 96, 129, 1),
+                                       (20_003, 384, 2048, 10), (5_000, 32, 4096, 1024), (30_001, 768, 200, 100)])
+def test_scores_path_matches_oracle(n, d, nq, k):
+    """A large batch over a short corpus: the matrix-core kernel writes every score and one workgroup per
+    query selects (path "gemm-scores").  Row counts that are not multiples of 4 take the scalar stores; masks,
+    thresholds, explicit ids and exact ties go through the selection kernel's rules."""
+    from oracle import flat
+    from rag_amd import DeviceIndex
+    rng = np.random.default_rng(n + nq + k)
+    X = _unit(rng, n, d)
+    X[n // 2: n // 2 + 5] = X[3]                           # exact ties: lower row first
+    Q = _unit(rng, nq, d)
+    Q[0] = X[3]
+    ids = rng.permutation(4 * n)[:n].astype(np.int64)
+    idx = DeviceIndex(d, metric="ip")
+    idx.add(X[: n // 3], ids=ids[: n // 3])
+    idx.add(X[n // 3:], ids=ids[n // 3:])
+    D, I = idx.search(Q, k)
+    assert idx.last_path == "gemm-scores"
+    _check(D, I, X, Q, k, ids=ids)
+    if k >= 6:
+        assert I[0, :6].tolist() == [int(ids[3])] + [int(v) for v in ids[n // 2: n // 2 + 5]]
+    mask = (rng.uniform(size=n) < 0.3).astype(np.uint8)
+    D, I = idx.search(Q, k, row_mask=mask, min_score=0.05)
+    assert idx.last_path == "gemm-scores"
+    _check(D, I, X, Q, k, ids=ids, row_mask=mask, min_score=0.05)
+    idx.set_active(np.arange(0, n, 2), False)
+    alive = np.ones(n, np.uint8)
+    alive[::2] = 0
+    D, I = idx.search(Q, k)
+    _check(D, I, X, Q, k, ids=ids, row_mask=alive)
+    D2, I2 = idx.search(Q, k)                              # the same answer twice
+    assert np.array_equal(D, D2) and np.array_equal(I, I2)
     idx.close()
