@@ -13,7 +13,10 @@ from bench import make_corpus, make_queries
 from rag_amd import DeviceIndex
 
 dev = torch.device("cuda", 0)
-for rows, dim, nq, k in ((16384, 1024, 4096, 64), (16384, 1024, 1024, 64), (65536, 768, 4096, 10), (100_000, 384, 4096, 10), (4096, 1024, 4096, 10)):
+shapes = ((16384, 1024, 4096, 64), (16384, 1024, 1024, 64), (65536, 768, 4096, 10), (100_000, 384, 4096, 10), (4096, 1024, 4096, 10))
+if os.environ.get("SHAPES"):        # SHAPES="rows:dim:nq:k,..."
+    shapes = tuple(tuple(int(v) for v in t.split(":")) for t in os.environ["SHAPES"].split(","))
+for rows, dim, nq, k in shapes:
     X = make_corpus(torch, 0, rows, dim, dev)
     Q = make_queries(torch, nq, dim, dev)
     idx = DeviceIndex(dim, metric="ip")

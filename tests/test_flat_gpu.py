@@ -352,3 +352,42 @@ def test_host_threads_may_share_an_index():
     assert not any(th.is_alive() for th in threads)
     assert errors == []
     idx.close()
+
+
+def test_device_search_can_be_captured_in_a_hip_graph():
+    """rag_index_search_device enqueues kernels and memsets only once its workspaces have their size (a warm-up
+    call on the stream that is captured): the call can be recorded into a HIP graph and replayed with new query
+    contents, flat and IVF, with the answers of the direct call."""
+    import torch
+    from rag_amd import DeviceIndex
+    dev = torch.device("cuda", 0)
+    g0 = torch.Generator(device=dev)
+    g0.manual_seed(5)
+    n, d, k = 60_000, 256, 10
+    X = torch.nn.functional.normalize(torch.randn(n, d, device=dev, generator=g0), dim=1)
+    Q = torch.nn.functional.normalize(torch.randn(8, d, device=dev, generator=g0), dim=1)
+    flat_idx = DeviceIndex(d, metric="ip")
+    flat_idx.add(X)
+    ivf_idx = DeviceIndex(d, metric="ip", kind="ivf")
+    ivf_idx.train_ivf(64, centroids=X[:64].cpu().numpy())
+    ivf_idx.add(X)
+    ivf_idx.search(Q[:1], k, nprobe=8)                     # packs the lists (synchronises: not part of a capture)
+    for idx, kw in ((flat_idx, {}), (ivf_idx, {"nprobe": 8})):
+        q = Q[0:1].clone()
+        D = torch.empty((1, k), dtype=torch.float32, device=dev)
+        I = torch.empty((1, k), dtype=torch.int64, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(side):
+            idx.search_into(q, k, D.data_ptr(), I.data_ptr(), **kw)
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            idx.search_into(q, k, D.data_ptr(), I.data_ptr(), **kw)
+        for j in range(1, 8):
+            q.copy_(Q[j:j + 1])
+            graph.replay()
+            torch.cuda.synchronize()
+            Dd, Id = idx.search(Q[j:j + 1], k, **kw)
+            assert torch.equal(I, Id) and torch.equal(D, Dd), (idx.kind, j)
+        del graph
+        idx.close()
