@@ -42,8 +42,9 @@ enum rag_status {
  * (call site :213-222).  The rows are ranked on the same scan / matrix-core kernels by
  * q.x - |x|^2 / 2 (a row stores -|x|^2 / 2 in an extra column, its stride is a multiple of 32
  * floats); the k kept rows are then re-scored as sums of squared fp32 differences, so a row equal
- * to the query is at distance exactly 0.  Entry points that rank by similarity (segment search, the
- * fusion + MMR call, rag_multi_*, adopt, the bf16 first pass) return RAG_ERR_UNSUPPORTED. */
+ * to the query is at distance exactly 0.  rag_multi_* merges the devices' answers nearest first.
+ * Segment search and the fusion + MMR call rank by similarity and return RAG_ERR_UNSUPPORTED, as do
+ * adopt and the bf16 first pass (an L2 row is wider than the caller's). */
 enum rag_metric { RAG_METRIC_IP = 0, RAG_METRIC_COSINE = 1, RAG_METRIC_L2 = 2 };
 
 /* FLAT = exhaustive scan (FAISS IndexFlatIP semantics); IVF = coarse lists

@@ -93,7 +93,7 @@ struct Piece {
 }  // namespace
 
 struct rag_multi {
-    int dim = 0, kind = 0;
+    int dim = 0, kind = 0, metric = 0;
     std::vector<rag_index_t*> shard;
     std::vector<int> device;
     std::vector<long long> rows;                    // rows per shard
@@ -137,10 +137,10 @@ int rag_multi_create(int dim, int metric, int kind, int n_devices, const int* de
     *out = nullptr;
     if (n_devices < 1 || n_devices > 64) return fail(RAG_ERR_INVALID, "n_devices must be in [1, 64]");
     if (!device_ids) return fail(RAG_ERR_INVALID, "device_ids is NULL");
-    if (metric == RAG_METRIC_L2) return fail(RAG_ERR_UNSUPPORTED, "the per-device answers are merged best similarity first: not available with the L2 metric");
     std::unique_ptr<rag_multi> h(new rag_multi());
     h->dim = dim;
     h->kind = kind;
+    h->metric = metric;
     for (int s = 0; s < n_devices; ++s) {
         rag_index_t* idx = nullptr;
         if (int rc = rag_index_create(dim, metric, kind, device_ids[s], &idx)) {
@@ -279,14 +279,15 @@ int rag_multi_search(rag_multi_t* h, int64_t nq, const float* q, int k, float mi
         float* d = Ds.data() + (size_t)s * per;
         int64_t* i = Is.data() + (size_t)s * per;
         if (h->rows[(size_t)s] == 0) {
-            std::fill(d, d + per, -FLT_MAX);
+            std::fill(d, d + per, h->metric == RAG_METRIC_L2 ? FLT_MAX : -FLT_MAX);
             std::fill(i, i + per, (int64_t)-1);
             return (int)RAG_OK;
         }
         return rag_index_search(h->shard[(size_t)s], nq, q, k, min_score, nprobe, row_mask ? mask[(size_t)s].data() : nullptr, d, i);
     });
     if (rc != RAG_OK) return rc;
-    // k-way merge of S sorted lists per query: score descending, ties to the lower id
+    // k-way merge of S sorted lists per query: score descending (L2: distance ascending), ties to the lower id
+    const bool nearest = h->metric == RAG_METRIC_L2;
     std::vector<size_t> head(S);
     for (int64_t qi = 0; qi < nq; ++qi) {
         std::fill(head.begin(), head.end(), (size_t)0);
@@ -300,11 +301,11 @@ int rag_multi_search(rag_multi_t* h, int64_t nq, const float* q, int k, float mi
                 const int64_t id = Is[at];
                 if (id < 0) { head[s] = (size_t)k; continue; }        // the rest of this list is padding
                 const float sc = Ds[at];
-                if (best < 0 || sc > bs || (sc == bs && id < bi)) { best = (int)s; bs = sc; bi = id; }
+                if (best < 0 || (nearest ? sc < bs : sc > bs) || (sc == bs && id < bi)) { best = (int)s; bs = sc; bi = id; }
             }
             float* d = D + (size_t)qi * k + j;
             int64_t* i = I + (size_t)qi * k + j;
-            if (best < 0) { *d = -FLT_MAX; *i = -1; continue; }
+            if (best < 0) { *d = nearest ? FLT_MAX : -FLT_MAX; *i = -1; continue; }
             *d = bs;
             *i = bi;
             ++head[(size_t)best];

@@ -34,8 +34,7 @@ class DeviceIndex:
 
     An 'l2' index (flat only) answers with SQUARED distances, smallest first, empty slots as
     ``(-1, FLT_MAX)``; its ``min_score`` argument is the largest squared distance to return (None or a
-    negative value: no limit).  Segment search, the fusion pipeline and the several-GPU indexes rank by
-    similarity and refuse it."""
+    negative value: no limit).  Segment search and the fusion pipeline rank by similarity and refuse it."""
 
     def __init__(self, dim: int, metric: str = "cosine", kind: str = "flat", device: int = 0):
         metrics = {"ip": _lib.METRIC_IP, "dot": _lib.METRIC_IP, "cosine": _lib.METRIC_COSINE, "l2": _lib.METRIC_L2}
@@ -315,7 +314,7 @@ class MultiDeviceIndex:
     ``devices`` may name a GPU more than once.  numpy in, numpy out, like ``DeviceIndex.search``."""
 
     def __init__(self, dim: int, devices: Sequence[int], metric: str = "ip", kind: str = "flat"):
-        metrics = {"ip": _lib.METRIC_IP, "dot": _lib.METRIC_IP, "cosine": _lib.METRIC_COSINE, "l2": _lib.METRIC_L2}   # 'l2': refused by the library
+        metrics = {"ip": _lib.METRIC_IP, "dot": _lib.METRIC_IP, "cosine": _lib.METRIC_COSINE, "l2": _lib.METRIC_L2}
         kinds = {"flat": _lib.KIND_FLAT, "ivf": _lib.KIND_IVF}
         if metric not in metrics or kind not in kinds:
             raise ValueError(f"unknown metric {metric!r} or index kind {kind!r}")
@@ -399,6 +398,8 @@ class MultiDeviceIndex:
         arguments and result as ``hybrid_mmr``; rows must have been added without explicit ids."""
         if self._explicit_ids:
             raise ValueError("hybrid_mmr needs row positions as ids: add rows without explicit ids")
+        if self.metric == "l2":
+            raise ValueError("the fusion divides similarities by their maximum: not available on an 'l2' index")
         return hybrid_mmr_over(self.search, self.reconstruct, len(self), q, topn, bm25_rows, bm25_scores,
                                device=self.devices[0], **kw)
 

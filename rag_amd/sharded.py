@@ -50,8 +50,9 @@ class ShardedIndex:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        if getattr(local_index, "metric", None) == "l2":
-            raise ValueError("the exchange merges best similarity first: an 'l2' index cannot be sharded")
+        # an 'l2' index answers with distances, nearest first: they travel negated, so that the merge's
+        # "larger first" (and its -FLT_MAX for an empty slot) holds, and are negated back after it
+        self.nearest_first = getattr(local_index, "metric", None) == "l2"
         self.index = local_index
         self.row_base = int(row_base)        # global position of the local index's first row (hybrid_mmr)
         if local_search is None:
@@ -85,9 +86,11 @@ class ShardedIndex:
         mine = self._send_buf
         i_ptr = mine.data_ptr()
         self.index.search_into(q, k, i_ptr + d_off, i_ptr, **kw)
+        if self.nearest_first:
+            mine[nq * k:].view(torch.float32)[: nq * k].neg_()
         self._all_gather(buf, mine)
-        return merge_topk_strided(self.world, nq, k, buf.data_ptr() + d_off, d_stride, buf.data_ptr(), i_stride,
-                                  q.device)
+        D, I = merge_topk_strided(self.world, nq, k, buf.data_ptr() + d_off, d_stride, buf.data_ptr(), i_stride, q.device)
+        return (D.neg_(), I) if self.nearest_first else (D, I)
 
     def _all_gather(self, out, mine):
         """The path's one exchange.  RCCL gathers device buffers in place; a gloo group (CPU
@@ -108,6 +111,8 @@ class ShardedIndex:
         D, I = self._search(q, k, **kw)
         if self.world == 1:
             return D, I
+        if self.nearest_first:
+            D = -D
         was_numpy = isinstance(D, np.ndarray)
         if was_numpy:
             D, I = torch.from_numpy(D), torch.from_numpy(I)
@@ -124,6 +129,8 @@ class ShardedIndex:
         I_all = gathered[:, 0].contiguous()
         D_all = gathered[:, 1].to(torch.int32).view(torch.float32).contiguous()
         Dm, Im = self._merge(D_all, I_all)
+        if self.nearest_first:
+            Dm = -Dm
         if was_numpy:
             return Dm.cpu().numpy(), Im.cpu().numpy()
         return Dm, Im
@@ -155,6 +162,8 @@ class ShardedIndex:
         the local index's id base; keyword arguments and result as ``rag_amd.index.hybrid_mmr``."""
         import torch
         from .index import hybrid_mmr_over
+        if self.nearest_first:
+            raise ValueError("the fusion divides similarities by their maximum: not available on an 'l2' index")
         n_total = torch.tensor([len(self.index)], dtype=torch.int64)
         if self.world > 1:
             if self.dist.get_backend(self.group) != "gloo":

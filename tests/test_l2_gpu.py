@@ -114,11 +114,67 @@ def test_l2_is_refused_where_answers_are_ranked_by_similarity():
         idx.search_segments(X[:1], [(0, 100)], 5)
     with pytest.raises(RagHipError):
         hybrid_mmr(idx, X[0], 20, np.zeros(0, np.int64), np.zeros(0))
-    with pytest.raises(RagHipError):
-        MultiDeviceIndex(64, [0, 0], metric="l2")
+    multi = MultiDeviceIndex(64, [0, 0], metric="l2")
     with pytest.raises(ValueError):
-        ShardedIndex(idx)
+        multi.hybrid_mmr(X[0], 20, np.zeros(0, np.int64), np.zeros(0))
+    multi.close()
+    with pytest.raises(ValueError):
+        ShardedIndex(idx).hybrid_mmr(X[0], 20, np.zeros(0, np.int64), np.zeros(0))
     idx.close()
+
+
+@pytest.mark.parametrize("shards,n,d,nq,k", [(2, 9_000, 64, 1, 10), (3, 40_000, 384, 40, 10), (5, 20_003, 100, 300, 64)])
+def test_l2_over_several_devices_equals_one_index(shards, n, d, nq, k):
+    """rag_multi_* with the L2 metric: the devices' answers merged nearest first (ties to the lower id), empty
+    slots as (-1, FLT_MAX); and the sharded exchange (distances travel negated through the one merge) replayed
+    for the same shards on one GPU."""
+    import torch
+    from oracle import flat
+    from rag_amd import DeviceIndex, MultiDeviceIndex
+    from rag_amd.sharded import ShardedIndex, shard_range
+    rng = np.random.default_rng(shards + n)
+    X = _rows(rng, n, d, 2.0)
+    X[n - 1] = X[2]                                           # equal distances across shards
+    Q = _rows(rng, nq, d, 2.0)
+    Q[0] = X[2]
+    multi = MultiDeviceIndex(d, [0] * shards, metric="l2")
+    multi.add(X[: n // 2])
+    multi.add(X[n // 2:])
+    D, I = multi.search(Q, k)
+    Dr, Ir = flat.flat_l2_search(X, Q, k)
+    assert flat.compare_topk_l2(D, I, Dr, Ir, rtol=RTOL, atol=_atol(X, Q)) == []
+    assert I[0, 0] == 2 and I[0, 1] == n - 1 and D[0, 0] == 0.0 and D[0, 1] == 0.0
+    lim = float(np.median(D[:, k // 2]))
+    mask = (rng.uniform(size=n) < 0.5).astype(np.uint8)
+    D2, I2 = multi.search(Q, k, min_score=lim, row_mask=mask)
+    assert flat.compare_topk_l2(D2, I2, *flat.flat_l2_search(X, Q, k, max_dist2=lim, row_mask=mask), rtol=RTOL, atol=_atol(X, Q)) == []
+    multi.close()
+    # the per-rank step of the sharded search; the collective is the stand-in of test_sharded_device_gpu.py, which
+    # places every rank's send slot where the all-gather would
+    from test_sharded_device_gpu import _Collective
+    qt = torch.from_numpy(Q).cuda()
+    parts = []
+    for r in range(shards):
+        lo, hi = shard_range(n, r, shards)
+        idx = DeviceIndex(d, metric="l2")
+        idx.set_id_base(lo)
+        idx.add(X[lo:hi])
+        parts.append(idx)
+    slots = {}
+    for r in range(shards):
+        sh = ShardedIndex(parts[r])
+        sh.dist, sh.world, sh.rank = _Collective(r, shards, {}), shards, r
+        sh.search(qt, k)
+        slots[r] = sh.dist.sent
+    for r in range(shards):
+        sh = ShardedIndex(parts[r])
+        sh.dist, sh.world, sh.rank = _Collective(r, shards, {o: v for o, v in slots.items() if o != r}), shards, r
+        Ds, Is = sh.search(qt, k)
+        torch.cuda.synchronize()
+        assert flat.compare_topk_l2(Ds.cpu().numpy(), Is.cpu().numpy(), Dr, Ir, rtol=RTOL, atol=_atol(X, Q)) == [], r
+        assert Is[0, 0].item() == 2 and Is[0, 1].item() == n - 1 and Ds[0, 1].item() == 0.0
+    for p in parts:
+        p.close()
 
 
 def test_optimizer_with_the_euclidean_metric():
