@@ -396,7 +396,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
         }
         qp[i] = Q4 + (long long)qr * ld4 + ((lane & 7) ^ ((brow >> 1) & 7));
     }
+    // A work item's last tile is ragged (a list of 780 rows has a fourth 256-row tile with 12 of them).  Its waves
+    // each load and multiply their own 64 rows of a tile (WQ == 1), so a wave whose rows all lie past the end of the
+    // list skips its loads, fragment reads and MFMAs for that tile and only takes the barriers.
+    static_assert(!TASKS || (WQ == 1 && APW * 8 == 64), "a wave of a work item loads the 64 tile rows it multiplies");
+    bool a_live = true;              // the tile xp points at has rows for this wave
     auto set_tile = [&](long long t) {
+        if constexpr (TASKS) a_live = row_lo + t * RT + wv * 64 < row_hi;
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
             long long r = row_lo + t * RT + arow[i];
@@ -410,8 +416,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
         unsigned char* Bb = reinterpret_cast<unsigned char*>(Bs + buf * TILEB) + wv * (BPW * 1024);
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xp[i] + kt * (GK / 4)),
-                                             (__attribute__((address_space(3))) void*)(Ab + i * 1024), 16, 0, A_AUX);
+            if (!TASKS || a_live)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xp[i] + kt * (GK / 4)),
+                                                 (__attribute__((address_space(3))) void*)(Ab + i * 1024), 16, 0, A_AUX);
             if (i < BPW)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qp[i < BPW ? i : 0] + kt * (GK / 4)),
                                                  (__attribute__((address_space(3))) void*)(Bb + i * 1024), 16, 0, 0);
@@ -446,6 +453,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
         // most of a block to land.
         constexpr int READS = 2 + NJ, MFMAS = 8 * NJ, NKB = GK / 8;
         f4 fa[2][2], fb[2][NJ];
+        const bool cur_live = !TASKS || (row_lo + t * RT + wv * 64 < row_hi);       // wave-uniform
         for (int kt = 0; kt < KT; ++kt, buf ^= 1) {
             const float* Ab = As + buf * TILEA + (wm * 64) * GK;
             const float* Bb = Bs + buf * TILEB + (wq * NJ * 32) * GK;
@@ -465,6 +473,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
                     if (DIAG & 1024) issue_load(0, buf ^ 1);       // same instructions, cache-resident source
                     else if (kt + 1 < KT) issue_load(kt + 1, buf ^ 1);
                     else if (t + 1 < t_end) { set_tile(t + 1); issue_load(0, buf ^ 1); }
+                }
+                if constexpr (TASKS) {
+                    if (!cur_live) continue;          // nothing of this tile belongs to the wave
                 }
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi) fa[0][mi] = *reinterpret_cast<const f4*>(Ab + mi * 32 * GK + foff[0]);
@@ -590,6 +601,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
                     }
             }
             continue;
+        }
+        if constexpr (TASKS) {
+            if (!cur_live) continue;
         }
         tile_epilogue<RT, QT, NJ>(a, acc, cand, s_thr, s_cnt, s_flag, m_valid, row_lo + t * RT + wm * 64, row_hi, wq * NJ * 32, l31, h, tg);
     }
