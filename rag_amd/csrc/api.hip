@@ -174,6 +174,10 @@ bool gemm_scores_supported(const rag_index* h, long long nq, int k);
 size_t gemm_scores_workspace(const rag_index* h, long long nq);
 int gemm_scores_search(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask, float* D,
                        long long* I, hipStream_t s);
+bool gemm_segments_supported(const rag_index* h, long long nq, int k);
+size_t gemm_segments_workspace(const rag_index* h, long long nq, int k);
+int gemm_segments_search(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask, float* D,
+                         long long* I, hipStream_t s);
 bool prefilter_scan_supported(const rag_index* h, long long nq, int k);       // gemm_topk.hip
 size_t prefilter_scan_workspace(const rag_index* h, int k);
 int prefilter_scan_search(rag_index* h, const float* qbuf, int k, float min_score, const uint8_t* mask,
@@ -299,6 +303,7 @@ size_t flat_search_workspace(const rag_index* h, long long nq, int k) {
     if (gemm_scores_supported(h, nq, k)) return gemm_scores_workspace(h, nq);
     if (use_narrow(h, nq, k)) return narrow_topk_workspace(h, nq, k);
     if (gemm_topk_supported(h, nq, k)) return gemm_topk_workspace(h, nq, k);
+    if (gemm_segments_supported(h, nq, k)) return gemm_segments_workspace(h, nq, k);
     if (prefilter_scan_supported(h, nq, k)) return prefilter_scan_workspace(h, k);
     return (size_t)((k > 64) ? 1 : 8) * scan_blocks(h, k) * 4 * k * sizeof(u64);
 }
@@ -315,6 +320,7 @@ int flat_search_prepared(rag_index* h, long long nq, const float* qbuf, int k, f
     if (gemm_scores_supported(h, nq, k)) return gemm_scores_search(h, nq, qbuf, k, min_score, mask, D, I, s);
     if (use_narrow(h, nq, k)) return narrow_topk_search(h, nq, qbuf, k, min_score, mask, D, I, s);
     if (gemm_topk_supported(h, nq, k)) return gemm_topk_search(h, nq, qbuf, k, min_score, mask, D, I, s);
+    if (gemm_segments_supported(h, nq, k)) return gemm_segments_search(h, nq, qbuf, k, min_score, mask, D, I, s);
     if (prefilter_scan_supported(h, nq, k)) return prefilter_scan_search(h, qbuf, k, min_score, mask, D, I, s);
     return flat_scan_search(h, nq, qbuf, k, min_score, mask, D, I, s);
 }
@@ -906,6 +912,18 @@ static int merge_topk_with_keys(int nlists, int64_t nq, int k, const float* D_de
     RAG_HIP_CHECK(launch_merge_keys(m, nq, s));
     return RAG_OK;
 }
+
+}  // extern "C"
+
+namespace rag {
+int merge_lists_device(int nlists, long long nq, int k, const float* D_dev, long long d_list_stride, const long long* I_dev,
+                       long long i_list_stride, float* D_out, long long* I_out, u64* keys, hipStream_t s) {
+    return merge_topk_with_keys(nlists, nq, k, D_dev, d_list_stride, reinterpret_cast<const int64_t*>(I_dev), i_list_stride, D_out,
+                                reinterpret_cast<int64_t*>(I_out), keys, s);
+}
+}  // namespace rag
+
+extern "C" {
 
 static int merge_topk_check(int nlists, int64_t nq, int k, const float* D_dev, int64_t& d_list_stride, const int64_t* I_dev,
                             int64_t& i_list_stride, float* D_out_dev, int64_t* I_out_dev) {

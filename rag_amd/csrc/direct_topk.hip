@@ -246,6 +246,8 @@ __global__ __launch_bounds__(1024) void direct_select_kernel(SelectArgs p) {
 
 int direct_select_launch(rag_index* h, long long nq, int k, float min_score, const uint8_t* mask, const float* scores, float* D,
                          long long* I, hipStream_t s);
+int direct_select_rows(long long nq, int n, int k, float min_score, const uint8_t* mask, const long long* row_ids, long long id_base,
+                       long long* rows_out, const float* scores, float* D, long long* I, hipStream_t s);
 
 bool direct_topk_supported(const rag_index* h, long long nq, int k) {
     static const int on = getenv("RAG_DIRECT_TOPK") ? atoi(getenv("RAG_DIRECT_TOPK")) : 1;          // measurement knob
@@ -278,18 +280,23 @@ int direct_topk_search(rag_index* h, long long nq, const float* qbuf, int k, flo
 // the k best of every query's n scores ([nq][n], n <= 32768): one selection workgroup per query
 int direct_select_launch(rag_index* h, long long nq, int k, float min_score, const uint8_t* mask, const float* scores, float* D,
                          long long* I, hipStream_t s) {
-    const int n = (int)h->n;
+    return direct_select_rows(nq, (int)h->n, k, min_score, mask, h->ids_dev, h->id_base, h->merge_rows_out, scores, D, I, s);
+}
+
+// the same for any table of n <= 32768 scores per query: row r is reported as row_ids[r], or id_base + r
+int direct_select_rows(long long nq, int n, int k, float min_score, const uint8_t* mask, const long long* row_ids, long long id_base,
+                       long long* rows_out, const float* scores, float* D, long long* I, hipStream_t s) {
     SelectArgs p = {};
     p.scores = scores;
     p.n = n;
     p.k = k;
     p.mask = mask;
     p.min_score = min_score;
-    p.row_ids = h->ids_dev;
-    p.id_base = h->id_base;
+    p.row_ids = row_ids;
+    p.id_base = id_base;
     p.D = D;
     p.I = I;
-    p.rows_out = h->merge_rows_out;
+    p.rows_out = rows_out;
     if (n <= 8 * 1024) hipLaunchKernelGGL(direct_select_kernel<8>, dim3((unsigned)nq), dim3(1024), 0, s, p);
     else if (n <= 16 * 1024) hipLaunchKernelGGL(direct_select_kernel<16>, dim3((unsigned)nq), dim3(1024), 0, s, p);
     else hipLaunchKernelGGL(direct_select_kernel<SEL_REG_MAX>, dim3((unsigned)nq), dim3(1024), 0, s, p);

@@ -1120,6 +1120,93 @@ int gemm_scores_search(rag_index* h, long long nq, const float* qbuf, int k, flo
 }
 
 // ---------------------------------------------------------------------------------------------
+// k above what the selecting kernel carries (64), 8 or more queries, any corpus: the in-kernel candidate buffers do not
+// scale to hundreds of keys per query, and the fallback used to be one full scan of the corpus PER QUERY (64 queries,
+// k = 100, 10M rows: 64 x 4.6 ms).  Path "gemm-segments" walks the corpus in segments of 32768 rows: the score-writing
+// kernel above fills the [queries x segment] score matrix, direct_select_kernel leaves every query's k best of the
+// segment (mask, threshold and ids applied there), and once all segments are done the k-way device merge of
+// rag_merge_topk_device reduces the per-segment lists -- ties to the lower slot, i.e. the lower row.  Queries go in
+// chunks so that the lists of a chunk stay a few hundred MB.  Cost: the matrix-core pass over the corpus plus a few per cent.
+int direct_select_rows(long long nq, int n, int k, float min_score, const uint8_t* mask, const long long* row_ids, long long id_base,
+                       long long* rows_out, const float* scores, float* D, long long* I, hipStream_t s);     // direct_topk.hip
+int merge_lists_device(int nlists, long long nq, int k, const float* D_dev, long long d_list_stride, const long long* I_dev,
+                       long long i_list_stride, float* D_out, long long* I_out, u64* keys, hipStream_t s);    // api.hip
+
+static long long seg_query_chunk(int k) { return k <= 256 ? 1024 : 256; }
+
+bool gemm_segments_supported(const rag_index* h, long long nq, int k) {
+    static const int min_nq = env_int_g("RAG_GEMM_SEGMENTS_MIN_NQ", 8);         // 0 switches the path off (measurement knob)
+    return min_nq > 0 && h->kind == RAG_KIND_FLAT && !h->prefilter && (h->ld % GK) == 0 && h->n >= 1024 && nq >= min_nq &&
+           k > GEMM_MAX_K && k <= 1024 && h->n <= ((long long)1 << 31) - SCORES_MAX_ROWS;
+}
+
+struct SegPlan {
+    long long nseg, qc;
+    size_t scores_bytes, d_bytes, i_bytes, keys_bytes;
+};
+static SegPlan seg_plan(const rag_index* h, long long nq, int k) {
+    SegPlan p;
+    p.nseg = (h->n + SCORES_MAX_ROWS - 1) / SCORES_MAX_ROWS;
+    p.qc = std::min<long long>(nq, seg_query_chunk(k));
+    const long long seg_rows = std::min<long long>(h->n, SCORES_MAX_ROWS);
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    p.scores_bytes = al((size_t)p.qc * seg_rows * sizeof(float));
+    p.d_bytes = al((size_t)p.nseg * p.qc * k * sizeof(float));
+    p.i_bytes = al((size_t)p.nseg * p.qc * k * sizeof(long long));
+    p.keys_bytes = al((size_t)p.nseg * p.qc * k * sizeof(u64));
+    return p;
+}
+size_t gemm_segments_workspace(const rag_index* h, long long nq, int k) {
+    const SegPlan p = seg_plan(h, nq, k);
+    return p.scores_bytes + p.d_bytes + p.i_bytes + p.keys_bytes;
+}
+
+int gemm_segments_search(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask, float* D,
+                         long long* I, hipStream_t s) {
+    const SegPlan p = seg_plan(h, nq, k);
+    const size_t qbytes = ((size_t)nq * h->ld * sizeof(float) + 255) & ~(size_t)255;
+    if (h->ws.bytes < qbytes + gemm_segments_workspace(h, nq, k)) return fail(RAG_ERR_INVALID, "internal: workspace not sized for the segment walk");
+    char* w = static_cast<char*>(h->ws.ptr) + qbytes;
+    float* scores = reinterpret_cast<float*>(w);
+    float* Dseg = reinterpret_cast<float*>(w + p.scores_bytes);
+    long long* Iseg = reinterpret_cast<long long*>(w + p.scores_bytes + p.d_bytes);
+    u64* keys = reinterpret_cast<u64*>(w + p.scores_bytes + p.d_bytes + p.i_bytes);
+    if (int rc = profile_begin(h, s)) return rc;
+    for (long long q0 = 0; q0 < nq; q0 += p.qc) {
+        const long long qc = std::min(p.qc, nq - q0);
+        const bool big = qc >= 512;                   // the 256 x 256 shape from 512 queries, 128 x 128 below
+        const int QT = big ? 256 : 128;
+        for (long long sg = 0; sg < p.nseg; ++sg) {
+            const long long lo = sg * SCORES_MAX_ROWS, rows = std::min<long long>(SCORES_MAX_ROWS, h->n - lo);
+            GemmArgs a = {};
+            a.X = h->X + (size_t)lo * h->ld;
+            a.Q = qbuf + (size_t)q0 * h->ld;
+            a.n = rows;
+            a.ntiles = (rows + QT - 1) / QT;
+            a.nq = (int)qc;
+            a.ld = h->ld;
+            a.k = k;
+            a.nqb = (int)((qc + QT - 1) / QT);
+            a.nqb_pad = a.nqb;
+            a.S = (int)std::max<long long>(1, std::min<long long>(a.ntiles, ((big ? 256 : 512) + a.nqb_pad - 1) / a.nqb_pad));
+            a.gq = 0;
+            a.outc = k;
+            a.trig = gemm_trig(QT, QT, GEMM_MAX_K);
+            a.scores = scores;
+            const int grid = a.nqb_pad * a.S;
+            if (int rc = big ? launch_gemm_store<256, 256, 8>(a, grid, h->device, s) : launch_gemm_store<128, 128, 4>(a, grid, h->device, s)) return rc;
+            if (int rc = direct_select_rows(qc, (int)rows, k, min_score, mask ? mask + lo : nullptr, h->ids_dev ? h->ids_dev + lo : nullptr,
+                                            h->id_base + lo, nullptr, scores, Dseg + (size_t)sg * qc * k, Iseg + (size_t)sg * qc * k, s))
+                return rc;
+        }
+        if (int rc = merge_lists_device((int)p.nseg, qc, k, Dseg, qc * k, Iseg, qc * k, D + (size_t)q0 * k, I + (size_t)q0 * k, keys, s)) return rc;
+    }
+    if (int rc = profile_end(h, s)) return rc;
+    h->last_path = "gemm-segments";
+    return RAG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // List-major IVF scan for large batches.  After the coarse step every query has nprobe lists; with
 // many queries a list is probed by several of them, and scanning per query would read it once for
 // each.  Here the (query, probe) pairs are grouped by list on the device, a work item is "up to 32

@@ -15,4 +15,6 @@ def flat_fp32_path(n, d, nq, k):
             return "narrow"
     if nq >= 5 and k <= 64 and ld % 32 == 0 and n >= 1:
         return "gemm"
+    if nq >= 8 and 64 < k <= 1024 and ld % 32 == 0 and n >= 1024:
+        return "gemm-segments"        # k beyond the selecting kernel: score matrix + selection per 32768-row segment, one merge
     return "scan"

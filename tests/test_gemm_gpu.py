@@ -138,3 +138,40 @@ def test_scores_path_matches_oracle(n, d, nq, k):
     D2, I2 = idx.search(Q, k)                              # the same answer twice
     assert np.array_equal(D, D2) and np.array_equal(I, I2)
     idx.close()
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(100_000, 128, 40, 100), (65_537, 64, 300, 200), (40_000, 96, 9, 1024), (200_000, 32, 1100, 65),
+                                       (32_769, 256, 8, 100), (1_500, 64, 20, 300), (98_304, 384, 600, 128)])
+def test_segments_path_matches_oracle(n, d, nq, k):
+    """k above 64 with 8 or more queries: the corpus is walked in segments of 32768 rows (score matrix on the matrix
+    cores, one selection workgroup per query and segment) and the per-segment lists are merged (path "gemm-segments").
+    Last segments of one row and of a few thousand, an exact tie across a segment boundary, masks, a threshold,
+    explicit ids, fewer hits than k."""
+    from rag_amd import DeviceIndex
+    rng = np.random.default_rng(n + nq + k)
+    X = _unit(rng, n, d)
+    if n > 40_000:
+        X[32_768 + 5] = X[7]                              # equal scores in two segments: the lower row first
+    Q = _unit(rng, nq, d)
+    Q[0] = X[7]
+    ids = rng.permutation(4 * n)[:n].astype(np.int64)
+    idx = DeviceIndex(d, metric="ip")
+    idx.add(X[: n // 3], ids=ids[: n // 3])
+    idx.add(X[n // 3:], ids=ids[n // 3:])
+    D, I = idx.search(Q, k)
+    assert idx.last_path == "gemm-segments"
+    _check(D, I, X, Q, k, ids=ids)
+    if n > 40_000:
+        assert I[0, 0] == ids[7] and I[0, 1] == ids[32_768 + 5] and D[0, 0] == D[0, 1]
+    mask = (rng.uniform(size=n) < 0.3).astype(np.uint8)
+    D, I = idx.search(Q, k, row_mask=mask, min_score=0.1)        # most queries end with fewer than k hits
+    assert idx.last_path == "gemm-segments"
+    _check(D, I, X, Q, k, ids=ids, row_mask=mask, min_score=0.1)
+    idx.set_active(np.arange(0, n, 3), False)
+    alive = np.ones(n, np.uint8)
+    alive[::3] = 0
+    D, I = idx.search(Q, k)
+    _check(D, I, X, Q, k, ids=ids, row_mask=alive)
+    D2, I2 = idx.search(Q, k)
+    assert np.array_equal(D, D2) and np.array_equal(I, I2)
+    idx.close()
