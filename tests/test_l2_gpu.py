@@ -29,7 +29,8 @@ def _atol(X, Q):
 
 
 @pytest.mark.parametrize("n,d,nq,k", [(1, 8, 1, 5), (700, 36, 3, 10), (20_000, 384, 1, 10), (40_000, 768, 1, 100), (30_000, 100, 7, 10),
-                                       (50_000, 768, 40, 10), (25_000, 127, 300, 20), (9_000, 1024, 1030, 5), (3_000, 31, 2, 1024)])
+                                       (50_000, 768, 40, 10), (25_000, 127, 300, 20), (9_000, 1024, 1030, 5), (3_000, 31, 2, 1024),
+                                       (70_000, 128, 40, 100), (16_384, 64, 300, 200)])      # k above 64 in a batch: segment walk, score matrix
 def test_l2_search_matches_oracle(n, d, nq, k):
     from oracle import flat
     from rag_amd import DeviceIndex
