@@ -363,6 +363,17 @@ int rag_index_hybrid_mmr_device(rag_index_t* h, const float* q_dev, int topn, fl
                                 const double* bm25_scores_dev, double w_sem, double w_bm25,
                                 int fuse_limit, double mmr_lambda, double mmr_threshold, int mmr_metric,
                                 int max_results, const rag_hybrid_out_t* out_dev, void* stream);
+/* the same for a batch of queries (no counterpart in the reference, whose search() answers one query per call,
+ * vector_db/search_manager.py:938-970 + :1620-1681; for callers that batch requests): ONE search of all nq queries for their
+ * topn semantic hits, then fusion and MMR query by query on the same stream.  q_dev [nq][dim]; every query brings nb keyword
+ * hits: bm25_rows_dev / bm25_scores_dev [nq][nb] (row positions outside the index are ignored, so a shorter list is padded
+ * with -1).  Results: ids_dev / scores_dev [nq][M] with M = min(max_results, fuse_limit, topn + nb), n_out_dev [nq]; ids past
+ * a query's count are -1.  Device memory throughout, enqueued on `stream`, not synchronised. */
+int rag_index_hybrid_mmr_batch_device(rag_index_t* h, int64_t nq, const float* q_dev, int topn, float min_score, int nprobe,
+                                      const uint8_t* row_mask_dev, int64_t nb, const int64_t* bm25_rows_dev,
+                                      const double* bm25_scores_dev, double w_sem, double w_bm25, int fuse_limit,
+                                      double mmr_lambda, double mmr_threshold, int mmr_metric, int max_results,
+                                      int64_t* ids_dev, double* scores_dev, int32_t* n_out_dev, void* stream);
 
 #ifdef __cplusplus
 }

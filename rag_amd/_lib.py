@@ -69,6 +69,8 @@ SIGNATURES = {
     "rag_mmr_select_rows": (_i32, [_vp, _i64, _vp, _vp, _f64, _f64, _i32, _i32, _vp, _vp]),
     "rag_index_hybrid_mmr": (_i32, [_vp, _vp, _i32, _f32, _i32, _vp, _i64, _vp, _vp, _f64, _f64, _i32, _f64, _f64, _i32,
                                     _i32, _vp]),
+    "rag_index_hybrid_mmr_batch_device": (_i32, [_vp, _i64, _vp, _i32, _f32, _i32, _vp, _i64, _vp, _vp, _f64, _f64, _i32, _f64, _f64,
+                                                  _i32, _i32, _vp, _vp, _vp, _vp]),
     "rag_index_hybrid_mmr_device": (_i32, [_vp, _vp, _i32, _f32, _i32, _vp, _i64, _vp, _vp, _f64, _f64, _i32, _f64, _f64,
                                            _i32, _i32, _vp, _vp]),
     "rag_multi_create": (_i32, [_i32, _i32, _i32, _i32, _vp, C.POINTER(_vp)]),

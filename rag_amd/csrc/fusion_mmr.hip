@@ -1039,6 +1039,10 @@ static int hybrid_check(rag_index* h, int topn, int64_t nb, int fuse_limit, int 
     return RAG_OK;
 }
 
+static int hybrid_tail(rag_index* h, const HybridPlan& pl, char* w, const float* D, const long long* rows, const long long* bm_rows_dev,
+                       const double* bm_scores_dev, double w_sem, double w_bm, double lambda, double thr, int metric,
+                       const rag_hybrid_out_t& dst, hipStream_t s);
+
 // everything after the staging of inputs; `w` = the plan's workspace, bm lists already at their device addresses
 static int hybrid_enqueue(rag_index* h, const HybridPlan& pl, char* w, const float* q_dev, float min_score, int nprobe,
                           const uint8_t* mask_dev, const long long* bm_rows_dev, const double* bm_scores_dev, double w_sem,
@@ -1052,6 +1056,13 @@ static int hybrid_enqueue(rag_index* h, const HybridPlan& pl, char* w, const flo
     h->merge_rows_out = nullptr;
     if (rc) return rc;
     if (h->n == 0) RAG_HIP_CHECK(hipMemsetAsync(rows, 0xFF, (size_t)pl.topn * 8, s));     // no hits: every row -1
+    return hybrid_tail(h, pl, w, D, rows, bm_rows_dev, bm_scores_dev, w_sem, w_bm, lambda, thr, metric, dst, s);
+}
+
+// fusion and MMR of ONE query given its semantic hits (scores D, row positions rows; -1 where a slot is empty)
+static int hybrid_tail(rag_index* h, const HybridPlan& pl, char* w, const float* D, const long long* rows, const long long* bm_rows_dev,
+                       const double* bm_scores_dev, double w_sem, double w_bm, double lambda, double thr, int metric,
+                       const rag_hybrid_out_t& dst, hipStream_t s) {
     // 2. fusion + relevance normalisation
     HybridArgs f = {};
     f.D = D; f.rows = rows; f.topn = pl.topn;
@@ -1191,6 +1202,60 @@ int rag_index_hybrid_mmr_device(rag_index_t* h, const float* q_dev, int topn, fl
                                 reinterpret_cast<const long long*>(bm25_rows_dev), bm25_scores_dev, w_sem, w_bm25, mmr_lambda,
                                 mmr_threshold, mmr_metric, *out_dev, s))
         return rc;
+    return ws_release(h, s);
+}
+
+int rag_index_hybrid_mmr_batch_device(rag_index_t* h, int64_t nq, const float* q_dev, int topn, float min_score, int nprobe,
+                                      const uint8_t* row_mask_dev, int64_t nb, const int64_t* bm25_rows_dev,
+                                      const double* bm25_scores_dev, double w_sem, double w_bm25, int fuse_limit, double mmr_lambda,
+                                      double mmr_threshold, int mmr_metric, int max_results, int64_t* ids_dev, double* scores_dev,
+                                      int32_t* n_out_dev, void* stream) {
+    rag_hybrid_out_t probe = {};
+    probe.ids = ids_dev; probe.scores = scores_dev; probe.n_out = n_out_dev;
+    if (int rc = hybrid_check(h, topn, nb, fuse_limit, max_results, mmr_metric, mmr_lambda, &probe)) return rc;
+    if (nq < 0) return fail(RAG_ERR_INVALID, "nq < 0");
+    if (nq == 0) return RAG_OK;
+    if (!q_dev || (nb > 0 && (!bm25_rows_dev || !bm25_scores_dev))) return fail(RAG_ERR_INVALID, "NULL buffer");
+    if (min_score != min_score) return fail(RAG_ERR_INVALID, "min_score is NaN");
+    RAG_LOCK_INDEX(h);
+    int prev = 0;
+    RAG_HIP_CHECK(hipGetDevice(&prev));
+    if (prev != h->device) RAG_HIP_CHECK(hipSetDevice(h->device));
+    struct Restore { int p, d; ~Restore() { if (p != d) (void)hipSetDevice(p); } } restore{prev, h->device};
+    const HybridPlan pl = hybrid_plan(h, topn, (int)nb, fuse_limit, max_results);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = ws_acquire(h, s)) return rc;
+    // [one query's fusion / MMR buffers | scores of every query's semantic hits | their row positions]
+    const size_t db = al256((size_t)nq * topn * sizeof(float)), ib = al256((size_t)nq * topn * sizeof(long long));
+    if (int rc = h->ws3.ensure(pl.total + db + ib)) return rc;
+    char* w = static_cast<char*>(h->ws3.ptr);
+    float* Dall = reinterpret_cast<float*>(w + pl.total);
+    long long* Rall = reinterpret_cast<long long*>(w + pl.total + db);
+    // 1. the semantic top-N of all queries as ONE search.  It leaves row positions (the id table and base are set aside for
+    //    it: the index is locked and they are read when a launch is built); ids are named when the hits are final
+    long long* const ids = h->ids_dev;
+    const long long base = h->id_base;
+    h->ids_dev = nullptr;
+    h->id_base = 0;
+    const int rc = search_device_enqueue(h, nq, q_dev, topn, min_score, nprobe, row_mask_dev, Dall, reinterpret_cast<int64_t*>(Rall), s);
+    h->ids_dev = ids;
+    h->id_base = base;
+    if (rc) return rc;
+    // 2. fusion and MMR query by query behind it on the same stream (each a few small launches; the buffers are reused in stream order)
+    const int M = pl.M;
+    RAG_HIP_CHECK(hipMemsetAsync(ids_dev, 0xFF, (size_t)nq * M * sizeof(int64_t), s));        // slots past a query's count: -1
+    RAG_HIP_CHECK(hipMemsetAsync(n_out_dev, 0, (size_t)nq * sizeof(int32_t), s));
+    for (int64_t i = 0; i < nq; ++i) {
+        rag_hybrid_out_t dst = {};
+        dst.ids = ids_dev + (size_t)i * M;
+        dst.scores = scores_dev + (size_t)i * M;
+        dst.n_out = n_out_dev + i;
+        if (int rc2 = hybrid_tail(h, pl, w, Dall + (size_t)i * topn, Rall + (size_t)i * topn,
+                                  nb > 0 ? reinterpret_cast<const long long*>(bm25_rows_dev) + (size_t)i * nb : nullptr,
+                                  nb > 0 ? bm25_scores_dev + (size_t)i * nb : nullptr, w_sem, w_bm25, mmr_lambda, mmr_threshold, mmr_metric,
+                                  dst, s))
+            return rc2;
+    }
     return ws_release(h, s);
 }
 

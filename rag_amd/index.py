@@ -496,6 +496,53 @@ def hybrid_mmr(index: "DeviceIndex", q, topn: int, bm25_rows, bm25_scores, *, fu
     return res
 
 
+def hybrid_mmr_batch(index: "DeviceIndex", q, topn: int, bm25_rows, bm25_scores, *, fuse_limit: Optional[int] = None,
+                     max_results: int = 10, semantic_weight: float = 0.65, bm25_weight: float = 0.35, mmr_lambda: float = 0.6,
+                     mmr_threshold: float = 0.8, mmr_metric: str = "cosine", min_score: Optional[float] = None, nprobe: int = 1,
+                     row_mask=None):
+    """``hybrid_mmr`` for a batch of queries on the device: ONE search of all queries for their ``topn`` semantic hits, then
+    fusion and MMR per query behind it on torch's current stream (rag_index_hybrid_mmr_batch_device).
+
+    ``q``: CUDA float32 ``[nq, dim]``; ``bm25_rows`` / ``bm25_scores``: CUDA ``[nq, nb]`` (int64 row positions, -1 pads a
+    shorter list; float64 scores).  Returns CUDA tensors ``(ids [nq, M] int64, -1 past a query's count; scores [nq, M]
+    float64, the fused scores; n_out [nq] int32)`` with ``M = min(max_results, fuse_limit, topn + nb)``; nothing is synchronised."""
+    import torch
+    if not _is_torch_cuda(q) or q.dtype != torch.float32 or q.dim() != 2 or q.shape[1] != index.dim:
+        raise ValueError(f"expected a CUDA float32 [nq, {index.dim}] tensor")
+    q = q.contiguous()
+    nq, dev = q.shape[0], q.device
+    bmr = bm25_rows.to(device=dev, dtype=torch.int64).reshape(nq, -1).contiguous()
+    bms = bm25_scores.to(device=dev, dtype=torch.float64).reshape(nq, -1).contiguous()
+    if bmr.shape != bms.shape:
+        raise ValueError("one BM25 score per row")
+    nb = bmr.shape[1]
+    topn = int(topn)
+    if fuse_limit is None:
+        fuse_limit = min(1024, topn + nb)
+    fuse_limit = int(fuse_limit)
+    m_out = min(int(max_results), fuse_limit, topn + nb)
+    ids = torch.empty((nq, m_out), dtype=torch.int64, device=dev)
+    scores = torch.zeros((nq, m_out), dtype=torch.float64, device=dev)
+    n_out = torch.empty(nq, dtype=torch.int32, device=dev)
+    m_ptr = None
+    if row_mask is not None:
+        if not _is_torch_cuda(row_mask) or row_mask.dtype != torch.uint8 or row_mask.numel() != len(index):
+            raise ValueError("row_mask must be a CUDA uint8 tensor with one byte per row")
+        row_mask = row_mask.contiguous()
+        m_ptr = C.c_void_p(row_mask.data_ptr())
+    ms = -FLT_MAX if min_score is None else float(min_score)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    check(lib.rag_index_hybrid_mmr_batch_device(index._h, nq, C.c_void_p(q.data_ptr()), topn, ms, int(nprobe), m_ptr, nb,
+                                                C.c_void_p(bmr.data_ptr()) if nb else None,
+                                                C.c_void_p(bms.data_ptr()) if nb else None, float(semantic_weight),
+                                                float(bm25_weight), fuse_limit, float(mmr_lambda), float(mmr_threshold),
+                                                _MMR_METRICS.get(mmr_metric, _lib.MMR_COSINE), int(max_results),
+                                                C.c_void_p(ids.data_ptr()), C.c_void_p(scores.data_ptr()),
+                                                C.c_void_p(n_out.data_ptr()), C.c_void_p(stream)))
+    ids._rag_keepalive = (q, bmr, bms, row_mask)
+    return ids, scores, n_out
+
+
 def hybrid_mmr_over(search, reconstruct, ntotal: int, q, topn: int, bm25_rows, bm25_scores, *,
                     fuse_limit: Optional[int] = None, max_results: int = 10, semantic_weight: float = 0.65,
                     bm25_weight: float = 0.35, mmr_lambda: float = 0.6, mmr_threshold: float = 0.8,
