@@ -1225,12 +1225,24 @@ int rag_index_hybrid_mmr_batch_device(rag_index_t* h, int64_t nq, const float* q
     const HybridPlan pl = hybrid_plan(h, topn, (int)nb, fuse_limit, max_results);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc = ws_acquire(h, s)) return rc;
-    // [one query's fusion / MMR buffers | scores of every query's semantic hits | their row positions]
+    // the tails of different queries are independent and small (a few workgroups each): they are dealt over side streams
+    // between a fork and a join on the caller's stream (RAG_HYBRID_TAIL_STREAMS=1: all on the caller's stream)
+    static const int ns_env = env_int_m("RAG_HYBRID_TAIL_STREAMS", rag_index::kTailStreams);
+    const int NS = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(ns_env, (int)rag_index::kTailStreams), nq));
+    if (NS > 1) {
+        if (!h->tail_fork) RAG_HIP_CHECK(hipEventCreateWithFlags(&h->tail_fork, hipEventDisableTiming));
+        for (int j = 0; j < NS; ++j) {
+            if (!h->tail_stream[j]) RAG_HIP_CHECK(hipStreamCreateWithFlags(&h->tail_stream[j], hipStreamNonBlocking));
+            if (!h->tail_join[j]) RAG_HIP_CHECK(hipEventCreateWithFlags(&h->tail_join[j], hipEventDisableTiming));
+        }
+    }
+    // [fusion / MMR buffers, one set per stream | scores of every query's semantic hits | their row positions]
     const size_t db = al256((size_t)nq * topn * sizeof(float)), ib = al256((size_t)nq * topn * sizeof(long long));
-    if (int rc = h->ws3.ensure(pl.total + db + ib)) return rc;
+    const size_t tail_bytes = al256(pl.total);
+    if (int rc = h->ws3.ensure((size_t)NS * tail_bytes + db + ib)) return rc;
     char* w = static_cast<char*>(h->ws3.ptr);
-    float* Dall = reinterpret_cast<float*>(w + pl.total);
-    long long* Rall = reinterpret_cast<long long*>(w + pl.total + db);
+    float* Dall = reinterpret_cast<float*>(w + (size_t)NS * tail_bytes);
+    long long* Rall = reinterpret_cast<long long*>(w + (size_t)NS * tail_bytes + db);
     // 1. the semantic top-N of all queries as ONE search.  It leaves row positions (the id table and base are set aside for
     //    it: the index is locked and they are read when a launch is built); ids are named when the hits are final
     long long* const ids = h->ids_dev;
@@ -1245,17 +1257,29 @@ int rag_index_hybrid_mmr_batch_device(rag_index_t* h, int64_t nq, const float* q
     const int M = pl.M;
     RAG_HIP_CHECK(hipMemsetAsync(ids_dev, 0xFF, (size_t)nq * M * sizeof(int64_t), s));        // slots past a query's count: -1
     RAG_HIP_CHECK(hipMemsetAsync(n_out_dev, 0, (size_t)nq * sizeof(int32_t), s));
-    for (int64_t i = 0; i < nq; ++i) {
+    if (NS > 1) {
+        RAG_HIP_CHECK(hipEventRecord(h->tail_fork, s));
+        for (int j = 0; j < NS; ++j) RAG_HIP_CHECK(hipStreamWaitEvent(h->tail_stream[j], h->tail_fork, 0));
+    }
+    int rc2 = RAG_OK;
+    for (int64_t i = 0; i < nq && rc2 == RAG_OK; ++i) {
+        const int j = (int)(i % NS);
         rag_hybrid_out_t dst = {};
         dst.ids = ids_dev + (size_t)i * M;
         dst.scores = scores_dev + (size_t)i * M;
         dst.n_out = n_out_dev + i;
-        if (int rc2 = hybrid_tail(h, pl, w, Dall + (size_t)i * topn, Rall + (size_t)i * topn,
-                                  nb > 0 ? reinterpret_cast<const long long*>(bm25_rows_dev) + (size_t)i * nb : nullptr,
-                                  nb > 0 ? bm25_scores_dev + (size_t)i * nb : nullptr, w_sem, w_bm25, mmr_lambda, mmr_threshold, mmr_metric,
-                                  dst, s))
-            return rc2;
+        rc2 = hybrid_tail(h, pl, w + (size_t)j * tail_bytes, Dall + (size_t)i * topn, Rall + (size_t)i * topn,
+                          nb > 0 ? reinterpret_cast<const long long*>(bm25_rows_dev) + (size_t)i * nb : nullptr,
+                          nb > 0 ? bm25_scores_dev + (size_t)i * nb : nullptr, w_sem, w_bm25, mmr_lambda, mmr_threshold, mmr_metric,
+                          dst, NS > 1 ? h->tail_stream[j] : s);
     }
+    if (NS > 1) {         // the join is enqueued whatever happened above: the caller's stream must not run ahead of the side streams
+        for (int j = 0; j < NS; ++j) {
+            RAG_HIP_CHECK(hipEventRecord(h->tail_join[j], h->tail_stream[j]));
+            RAG_HIP_CHECK(hipStreamWaitEvent(s, h->tail_join[j], 0));
+        }
+    }
+    if (rc2) return rc2;
     return ws_release(h, s);
 }
 
