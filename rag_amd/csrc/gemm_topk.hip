@@ -1132,7 +1132,15 @@ int direct_select_rows(long long nq, int n, int k, float min_score, const uint8_
 int merge_lists_device(int nlists, long long nq, int k, const float* D_dev, long long d_list_stride, const long long* I_dev,
                        long long i_list_stride, float* D_out, long long* I_out, u64* keys, hipStream_t s);    // api.hip
 
-static long long seg_query_chunk(int k) { return k <= 256 ? 1024 : 256; }
+// queries per chunk: as many as keep a chunk's per-segment lists and merge keys (20 bytes per hit and segment) within
+// about 6 GB -- more queries per launch give every workgroup more tiles of a segment -- between 256 and 4096
+static long long seg_query_chunk(long long nseg, int k) {
+    static const long long budget = (long long)env_int_g("RAG_GEMM_SEGMENTS_BUDGET_MB", 6144) << 20;      // measurement knob
+    long long qc = budget / std::max<long long>(1, nseg * k * 20);
+    long long p2 = 256;
+    while (p2 * 2 <= qc && p2 < 4096) p2 *= 2;
+    return p2;
+}
 
 bool gemm_segments_supported(const rag_index* h, long long nq, int k) {
     static const int min_nq = env_int_g("RAG_GEMM_SEGMENTS_MIN_NQ", 8);         // 0 switches the path off (measurement knob)
@@ -1147,7 +1155,7 @@ struct SegPlan {
 static SegPlan seg_plan(const rag_index* h, long long nq, int k) {
     SegPlan p;
     p.nseg = (h->n + SCORES_MAX_ROWS - 1) / SCORES_MAX_ROWS;
-    p.qc = std::min<long long>(nq, seg_query_chunk(k));
+    p.qc = std::min<long long>(nq, seg_query_chunk(p.nseg, k));
     const long long seg_rows = std::min<long long>(h->n, SCORES_MAX_ROWS);
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     p.scores_bytes = al((size_t)p.qc * seg_rows * sizeof(float));
