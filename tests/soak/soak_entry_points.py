@@ -104,6 +104,41 @@ def pipeline_case(rng):
     idx.close()
 
 
+def pipeline_batch_case(rng):
+    d = int(rng.choice([64, 128, 256, 384]))
+    n = int(rng.integers(2_000, 90_000))
+    X, cent = tp._clustered(rng, n, d, ncl=int(rng.choice([5, 20, 60])), noise=float(rng.choice([0.05, 0.2, 0.5])))
+    nq = int(rng.choice([1, 3, 8, 12, 40, 130]))
+    topn = min(n, int(rng.choice([17, 64, 65, 100, 200, 300])))
+    nb = int(rng.choice([0, 10, 100]))
+    Q = cent[rng.integers(0, cent.shape[0], nq)] + 0.1 * rng.standard_normal((nq, d))
+    Q = (Q / np.linalg.norm(Q, axis=1, keepdims=True)).astype(np.float32)
+    idx = DeviceIndex(d, metric="ip")
+    if rng.uniform() < 0.4:
+        ids = rng.permutation(10 * n)[:n].astype(np.int64)
+        back = {int(v): r for r, v in enumerate(ids)}
+        idx.add(X, ids=ids)
+        to_rows, to_id = np.vectorize(lambda v: back[int(v)] if v >= 0 else -1), (lambda r: int(ids[r]))
+    else:
+        base = int(rng.choice([0, 7, 1 << 33]))
+        idx.set_id_base(base)
+        idx.add(X)
+        to_rows, to_id = (lambda I: np.where(I >= 0, I - base, -1)), (lambda r: r + base)
+    bm_rows = rng.integers(0, n, (nq, nb)).astype(np.int64)
+    if nb:
+        bm_rows[:, -3:] = -1
+    bm_scores = rng.gamma(2.0, 2.0, size=(nq, nb)) if rng.uniform() < 0.9 else np.zeros((nq, nb))
+    kw = {}
+    if rng.uniform() < 0.3:
+        kw["row_mask"] = (rng.uniform(size=n) < 0.6).astype(np.uint8)
+    if rng.uniform() < 0.3:
+        kw["min_score"] = 0.3
+    tp._check_batch(idx, X, Q, topn, bm_rows, bm_scores, to_rows, to_id, max_results=int(rng.choice([1, 10, 25])),
+                    lam=float(rng.choice([0.0, 0.5, 0.7, 1.0])), thr=float(rng.choice([0.0, 0.5, 0.8])),
+                    metric=str(rng.choice(["cosine", "dot_product", "euclidean"])), **kw)
+    idx.close()
+
+
 def ivf_pipeline_case(rng):
     d = int(rng.choice([64, 128, 256]))
     n = int(rng.integers(3_000, 40_000))
@@ -188,6 +223,7 @@ t0 = time.time()
 for seed in span("SEEDS", "0:40"):
     for name, fn in (("segments+fanout", lambda: segments_case(np.random.default_rng(5000 + seed))),
                      ("pipeline", lambda: [pipeline_case(np.random.default_rng(6000 + 10 * seed + j)) for j in range(3)]),
+                     ("pipeline batch", lambda: [pipeline_batch_case(np.random.default_rng(6500 + 10 * seed + j)) for j in range(2)]),
                      ("ivf pipeline", lambda: ivf_pipeline_case(np.random.default_rng(8000 + seed))),
                      ("several devices", lambda: multi_device_case(np.random.default_rng(9000 + seed))),
                      ("keyword", lambda: keyword_case(7000 + seed))):

@@ -201,14 +201,38 @@ def test_pipeline_argument_checks():
     idx.close()
 
 
+def _check_batch(idx, X, Q, topn, bm_rows, bm_scores, to_rows, to_id, *, max_results=10, lam=0.5, thr=0.8, metric="cosine", **kw):
+    """hybrid_mmr_batch against the oracle's fusion + MMR per query, fed with the scores of the same search as a plain call.
+    to_rows: ids of a search -> row positions (-1 kept); to_id: row position -> id."""
+    import torch
+    from rag_amd.index import hybrid_mmr_batch
+    nq, nb = bm_rows.shape
+    qt = torch.from_numpy(Q).cuda()
+    tkw = {k: (torch.from_numpy(v).cuda() if k == "row_mask" else v) for k, v in kw.items()}
+    got_ids, got_scores, got_n = hybrid_mmr_batch(idx, qt, topn, torch.from_numpy(bm_rows).cuda(), torch.from_numpy(bm_scores).cuda(),
+                                                  max_results=max_results, mmr_lambda=lam, mmr_threshold=thr, mmr_metric=metric, **tkw)
+    D, I = idx.search(qt, topn, **tkw)
+    torch.cuda.synchronize()
+    D, I = D.cpu().numpy(), I.cpu().numpy()
+    rows = to_rows(I)
+    gi, gs, gn = got_ids.cpu().numpy(), got_scores.cpu().numpy(), got_n.cpu().numpy()
+    fl = min(1024, topn + nb)
+    for i in range(nq):
+        f_rows, f_scores, _, _, picked, status = _oracle_tail(X, D[i], rows[i], bm_rows[i], bm_scores[i], fl, 0.65, 0.35, lam, thr,
+                                                               metric, max_results)
+        want_ids = [to_id(f_rows[p]) for p in picked]
+        assert gn[i] == len(picked), (idx.kind, nq, topn, i, int(gn[i]), len(picked))
+        assert gi[i, :gn[i]].tolist() == want_ids, (idx.kind, nq, topn, i)
+        assert np.array_equal(gs[i, :gn[i]], np.array([f_scores[p] for p in picked])), (idx.kind, nq, topn, i)
+        assert np.all(gi[i, gn[i]:] == -1)
+
+
 def test_batched_pipeline_equals_the_oracle_per_query():
     """rag_index_hybrid_mmr_batch_device: one search for every query's top-N, then fusion and MMR per query.  Each query's
     result is checked exactly against the oracle's fusion + MMR fed with the scores of that search (the same search as a plain
     call: 12 queries at k = 200 take the segment walk, 3 queries the scan), on a flat index with explicit ids and a mask, one
     with an id base, and an IVF index; keyword lists are padded with -1."""
-    import torch
     from rag_amd import DeviceIndex
-    from rag_amd.index import hybrid_mmr_batch
     rng = np.random.default_rng(21)
     n, d = 70_000, 128
     X, cent = _clustered(rng, n, d, ncl=30)
@@ -225,11 +249,11 @@ def test_batched_pipeline_equals_the_oracle_per_query():
     iv.train_ivf(nlist, centroids=C0)
     iv.add(X)
     mask = (rng.uniform(size=n) < 0.6).astype(np.uint8)
-    for idx, nq, topn, nb, kw, to_rows in (
-            (flat_ids, 12, 200, 60, {"row_mask": mask}, lambda I: np.vectorize(lambda v: back[int(v)] if v >= 0 else -1)(I)),
-            (flat_base, 3, 200, 100, {}, lambda I: np.where(I >= 0, I - 1000, -1)),
-            (flat_base, 9, 64, 0, {"min_score": 0.3}, lambda I: np.where(I >= 0, I - 1000, -1)),
-            (iv, 10, 150, 40, {"nprobe": 8}, lambda I: I)):
+    by_ids = (np.vectorize(lambda v: back[int(v)] if v >= 0 else -1), lambda r: int(ids[r]))
+    by_base = (lambda I: np.where(I >= 0, I - 1000, -1), lambda r: r + 1000)
+    plain = (lambda I: I, lambda r: r)
+    for idx, nq, topn, nb, kw, (to_rows, to_id) in ((flat_ids, 12, 200, 60, {"row_mask": mask}, by_ids), (flat_base, 3, 200, 100, {}, by_base),
+                                                    (flat_base, 9, 64, 0, {"min_score": 0.3}, by_base), (iv, 10, 150, 40, {"nprobe": 8}, plain)):
         Q = np.stack([cent[i % cent.shape[0]] / np.linalg.norm(cent[i % cent.shape[0]]) for i in range(nq)]).astype(np.float32)
         Q += 0.02 * rng.standard_normal(Q.shape).astype(np.float32)
         bm_rows = rng.integers(0, n, (nq, nb)).astype(np.int64)
@@ -237,24 +261,6 @@ def test_batched_pipeline_equals_the_oracle_per_query():
             bm_rows[:, -5:] = -1                                      # shorter lists, padded
             bm_rows[0, :] = -1                                        # a query without keyword hits
         bm_scores = rng.gamma(2.0, 2.0, size=(nq, nb))
-        qt = torch.from_numpy(Q).cuda()
-        tkw = {k: (torch.from_numpy(v).cuda() if k == "row_mask" else v) for k, v in kw.items()}
-        got_ids, got_scores, got_n = hybrid_mmr_batch(idx, qt, topn, torch.from_numpy(bm_rows).cuda(), torch.from_numpy(bm_scores).cuda(),
-                                                      max_results=10, mmr_lambda=0.5, mmr_threshold=0.8, **tkw)
-        D, I = idx.search(qt, topn, **tkw)
-        torch.cuda.synchronize()
-        D, I = D.cpu().numpy(), I.cpu().numpy()
-        rows = to_rows(I)
-        gi, gs, gn = got_ids.cpu().numpy(), got_scores.cpu().numpy(), got_n.cpu().numpy()
-        fl = min(1024, topn + nb)
-        for i in range(nq):
-            f_rows, f_scores, _, _, picked, status = _oracle_tail(X, D[i], rows[i], bm_rows[i], bm_scores[i], fl, 0.65, 0.35, 0.5, 0.8,
-                                                                   "cosine", 10)
-            want_rows = [f_rows[p] for p in picked]
-            want_ids = [int(ids[r]) if idx is flat_ids else (r + 1000 if idx is flat_base else r) for r in want_rows]
-            assert gn[i] == len(picked), (idx.kind, nq, i, int(gn[i]), len(picked))
-            assert gi[i, :gn[i]].tolist() == want_ids, (idx.kind, nq, i)
-            assert np.array_equal(gs[i, :gn[i]], np.array([f_scores[p] for p in picked])), (idx.kind, nq, i)
-            assert np.all(gi[i, gn[i]:] == -1)
+        _check_batch(idx, X, Q, topn, bm_rows, bm_scores, to_rows, to_id, **kw)
     for idx in (flat_ids, flat_base, iv):
         idx.close()
