@@ -398,11 +398,8 @@ int rag_index_free(rag_index_t* h) {
     if (h->active) (void)hipFree(h->active);
     for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
     if (h->ws_event) (void)hipEventDestroy(h->ws_event);
-    for (int j = 0; j < rag_index::kTailStreams; ++j) {
-        if (h->tail_stream[j]) { (void)hipStreamSynchronize(h->tail_stream[j]); (void)hipStreamDestroy(h->tail_stream[j]); }
-        if (h->tail_join[j]) (void)hipEventDestroy(h->tail_join[j]);
-    }
-    if (h->tail_fork) (void)hipEventDestroy(h->tail_fork);
+    if (h->tail_args_event) (void)hipEventDestroy(h->tail_args_event);
+    if (h->tail_args_host) (void)hipHostFree(h->tail_args_host);
     if (h->Xb) (void)hipFree(h->Xb);
     if (h->xb_maxnorm) (void)hipFree(h->xb_maxnorm);
     ivf_free(h);

@@ -121,7 +121,7 @@ struct MmrState {
 };
 
 // rows as fp64; cosine: divided by their norm (a zero norm counts as 1).  One wave per row.
-__global__ __launch_bounds__(64) void mmr_prepare_kernel(MmrArgs p, MmrState st) {
+__device__ __forceinline__ void mmr_prepare_body(const MmrArgs& p, const MmrState& st) {
     const int lane = threadIdx.x, d = p.d;
     const int c = blockIdx.x;
     if (p.n_dev && c >= *p.n_dev) return;
@@ -179,6 +179,8 @@ __global__ __launch_bounds__(64) void mmr_prepare_kernel(MmrArgs p, MmrState st)
     }
     if (lane == 0 && st.maxsim) { st.maxsim[c] = -INFINITY; st.alive[c] = 1; }
 }
+
+__global__ __launch_bounds__(64) void mmr_prepare_kernel(MmrArgs p, MmrState st) { mmr_prepare_body(p, st); }
 
 __device__ __forceinline__ bool mmr_better(double ob, int oi, double best, int bidx) {
     // the reference starts from the first remaining candidate and moves on strict '>': the
@@ -309,8 +311,7 @@ constexpr int SIM_TC = 8, SIM_TS = 8;      // candidates x selected rows per wor
 // rows of the tile stream through without a dependent-load chain.  Lanes past d hold zeros, which
 // leave an fma chain unchanged.
 template <int JL>
-__global__ __launch_bounds__(256) void mmr_simmat_kernel(const double* En, const int* n_dev, int n_max, int d, int metric,
-                                                         double* S, int ldS) {
+__device__ __forceinline__ void mmr_simmat_body(const double* En, const int* n_dev, int n_max, int d, int metric, double* S, int ldS) {
     const int n = n_dev ? *n_dev : n_max;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // the matrix is symmetric bit for bit (a product and a squared difference do not depend on the order of
@@ -409,6 +410,12 @@ __global__ __launch_bounds__(256) void mmr_simmat_kernel(const double* En, const
     }
 }
 
+template <int JL>
+__global__ __launch_bounds__(256) void mmr_simmat_kernel(const double* En, const int* n_dev, int n_max, int d, int metric,
+                                                         double* S, int ldS) {
+    mmr_simmat_body<JL>(En, n_dev, n_max, d, metric, S, ldS);
+}
+
 struct MmrSelArgs {
     const double* S;      // [n][ldS] pair similarities
     int ldS;
@@ -428,7 +435,7 @@ struct MmrSelArgs {
     double* out_scores;
 };
 
-__global__ __launch_bounds__(1024) void mmr_select_kernel(MmrSelArgs p) {
+__device__ __forceinline__ void mmr_select_body(const MmrSelArgs& p) {
     __shared__ double s_b[16];
     __shared__ int s_i[16];
     __shared__ int s_sel;
@@ -490,6 +497,8 @@ __global__ __launch_bounds__(1024) void mmr_select_kernel(MmrSelArgs p) {
     if (tid == 0) *p.n_out = rounds;
 }
 
+__global__ __launch_bounds__(1024) void mmr_select_kernel(MmrSelArgs p) { mmr_select_body(p); }
+
 // ---------------------------------------------------------------------------
 // Hybrid fusion of a semantic hit list with a keyword (BM25) list, both already on the device
 // (vector_db/search_manager.py:1023-1101 and the caller's sort + cut, :969-970), followed by the
@@ -521,7 +530,7 @@ struct HybridArgs {
     int* status;                 // 0 fused, 1 zero maximum (semantic list returned)
 };
 
-__global__ __launch_bounds__(1024) void hybrid_fuse_kernel(HybridArgs p) {
+__device__ __forceinline__ void hybrid_fuse_body(const HybridArgs& p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int NC = p.topn + p.nb;                       // candidate slots
@@ -771,6 +780,29 @@ __global__ __launch_bounds__(1024) void hybrid_fuse_kernel(HybridArgs p) {
     if (tid == 0) { *p.n_fused = m; *p.status = zero_div ? 1 : 0; }
     RAG_STAMP(6);
 }
+
+__global__ __launch_bounds__(1024) void hybrid_fuse_kernel(HybridArgs p) { hybrid_fuse_body(p); }
+
+// The same four stages for a batch of queries: blockIdx.y names the query, whose arguments (the structs the single-query
+// launches take by value) sit in an array in device memory.  The bodies are the single-query ones.
+struct TailArgs {
+    HybridArgs f;
+    MmrArgs p;
+    MmrSelArgs sel;
+    double* S;            // [n_max][n_max] pair matrix of this query
+    int n_max;
+};
+__global__ __launch_bounds__(1024) void hybrid_fuse_batch_kernel(const TailArgs* t) { hybrid_fuse_body(t[blockIdx.y].f); }
+__global__ __launch_bounds__(64) void mmr_prepare_batch_kernel(const TailArgs* t) {
+    const MmrState none = {};
+    mmr_prepare_body(t[blockIdx.y].p, none);
+}
+template <int JL>
+__global__ __launch_bounds__(256) void mmr_simmat_batch_kernel(const TailArgs* t) {
+    const TailArgs& a = t[blockIdx.y];
+    mmr_simmat_body<JL>(a.p.En, a.p.n_dev, a.n_max, a.p.d, a.p.metric, a.S, a.n_max);
+}
+__global__ __launch_bounds__(1024) void mmr_select_batch_kernel(const TailArgs* t) { mmr_select_body(t[blockIdx.y].sel); }
 
 static size_t hybrid_fuse_lds(int topn, int nb) {
     const size_t NC = (size_t)topn + nb;
@@ -1059,12 +1091,14 @@ static int hybrid_enqueue(rag_index* h, const HybridPlan& pl, char* w, const flo
     return hybrid_tail(h, pl, w, D, rows, bm_rows_dev, bm_scores_dev, w_sem, w_bm, lambda, thr, metric, dst, s);
 }
 
-// fusion and MMR of ONE query given its semantic hits (scores D, row positions rows; -1 where a slot is empty)
-static int hybrid_tail(rag_index* h, const HybridPlan& pl, char* w, const float* D, const long long* rows, const long long* bm_rows_dev,
-                       const double* bm_scores_dev, double w_sem, double w_bm, double lambda, double thr, int metric,
-                       const rag_hybrid_out_t& dst, hipStream_t s) {
-    // 2. fusion + relevance normalisation
-    HybridArgs f = {};
+// the arguments of the fusion and MMR stages of ONE query given its semantic hits (scores D, row positions rows; -1 where a
+// slot is empty); `w` = that query's set of the plan's buffers
+static TailArgs hybrid_tail_args(rag_index* h, const HybridPlan& pl, char* w, const float* D, const long long* rows,
+                                 const long long* bm_rows_dev, const double* bm_scores_dev, double w_sem, double w_bm, double lambda,
+                                 double thr, int metric, const rag_hybrid_out_t& dst) {
+    TailArgs t = {};
+    // fusion + relevance normalisation
+    HybridArgs& f = t.f;
     f.D = D; f.rows = rows; f.topn = pl.topn;
     f.bm_rows = bm_rows_dev; f.bm_scores = bm_scores_dev; f.nb = pl.nb; f.nrows = h->n;
     f.wa = w_sem; f.wb = w_bm; f.limit = pl.L;
@@ -1077,16 +1111,8 @@ static int hybrid_tail(rag_index* h, const HybridPlan& pl, char* w, const float*
     int* counts = reinterpret_cast<int*>(w + pl.o_res + pl.res_counts);       // [n_out, n_fused, status]
     f.n_fused = dst.n_fused ? dst.n_fused : counts + 1;
     f.status = dst.status ? dst.status : counts + 2;
-    const size_t lds = hybrid_fuse_lds(pl.topn, pl.nb);
-    static bool attr_set[64] = {};
-    if (lds > 48 * 1024 && !attr_set[h->device & 63]) {
-        RAG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(hybrid_fuse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set[h->device & 63] = true;
-    }
-    hipLaunchKernelGGL(hybrid_fuse_kernel, dim3(1), dim3(1024), lds, s, f);
-    RAG_HIP_CHECK(hipGetLastError());
-    // 3. MMR over the fused candidates, vectors read from the index rows
-    MmrArgs p = {};
+    // MMR over the fused candidates, vectors read from the index rows
+    MmrArgs& p = t.p;
     p.X = h->X;
     p.rows = f.f_rows;
     p.pos = h->kind == RAG_KIND_IVF ? h->ivf.pos_dev : nullptr;
@@ -1098,14 +1124,68 @@ static int hybrid_tail(rag_index* h, const HybridPlan& pl, char* w, const float*
     p.max_results = pl.M;
     p.out_idx = dst.picked ? dst.picked : reinterpret_cast<int*>(w + pl.o_res + pl.res_picked);
     p.n_out = dst.n_out;
-    MmrSelArgs sel = {};
+    t.S = reinterpret_cast<double*>(w + pl.o_S);
+    t.n_max = pl.L;
+    MmrSelArgs& sel = t.sel;
+    sel.S = t.S;
+    sel.ldS = pl.L;
+    sel.rel = p.rel;
+    sel.n_dev = p.n_dev;
+    sel.n_max = pl.L;
+    sel.lambda = lambda;
+    sel.threshold = thr;
+    sel.max_results = pl.M;
+    sel.out_idx = p.out_idx;
+    sel.n_out = p.n_out;
     sel.cand_rows = f.f_rows;
     sel.cand_score = f.f_score;
     sel.row_ids = h->ids_dev;
     sel.id_base = h->id_base;
     sel.out_ids = reinterpret_cast<long long*>(dst.ids);
     sel.out_scores = dst.scores;
-    return enqueue_mmr_sim(p, pl.L, reinterpret_cast<double*>(w + pl.o_S), sel, s);
+    return t;
+}
+
+static int hybrid_fuse_attr(rag_index* h, size_t lds) {
+    static bool attr_set[64] = {};
+    if (lds > 48 * 1024 && !attr_set[h->device & 63]) {
+        RAG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(hybrid_fuse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RAG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(hybrid_fuse_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[h->device & 63] = true;
+    }
+    return RAG_OK;
+}
+
+// fusion and MMR of ONE query: four small launches
+static int hybrid_tail(rag_index* h, const HybridPlan& pl, char* w, const float* D, const long long* rows, const long long* bm_rows_dev,
+                       const double* bm_scores_dev, double w_sem, double w_bm, double lambda, double thr, int metric,
+                       const rag_hybrid_out_t& dst, hipStream_t s) {
+    const TailArgs t = hybrid_tail_args(h, pl, w, D, rows, bm_rows_dev, bm_scores_dev, w_sem, w_bm, lambda, thr, metric, dst);
+    const size_t lds = hybrid_fuse_lds(pl.topn, pl.nb);
+    if (int rc = hybrid_fuse_attr(h, lds)) return rc;
+    hipLaunchKernelGGL(hybrid_fuse_kernel, dim3(1), dim3(1024), lds, s, t.f);
+    RAG_HIP_CHECK(hipGetLastError());
+    return enqueue_mmr_sim(t.p, pl.L, t.S, t.sel, s);
+}
+
+// the same four stages for nq queries whose arguments sit in device memory (args_dev[0 .. nq)): one launch per stage
+static int hybrid_tail_batch(rag_index* h, const HybridPlan& pl, const TailArgs* args_dev, int nq, hipStream_t s) {
+    const size_t lds = hybrid_fuse_lds(pl.topn, pl.nb);
+    if (int rc = hybrid_fuse_attr(h, lds)) return rc;
+    const unsigned y = (unsigned)nq;
+    hipLaunchKernelGGL(hybrid_fuse_batch_kernel, dim3(1, y), dim3(1024), lds, s, args_dev);
+    hipLaunchKernelGGL(mmr_prepare_batch_kernel, dim3((unsigned)pl.L, y), dim3(64), 0, s, args_dev);
+    const int tiles = (pl.L + SIM_TC - 1) / SIM_TC;
+    const dim3 grid((unsigned)(tiles * (tiles + 1) / 2), y);
+    const int jl = (h->dim + 63) / 64;
+    if (jl <= 4) hipLaunchKernelGGL(mmr_simmat_batch_kernel<4>, grid, dim3(256), 0, s, args_dev);
+    else if (jl <= 8) hipLaunchKernelGGL(mmr_simmat_batch_kernel<8>, grid, dim3(256), 0, s, args_dev);
+    else if (jl <= 12) hipLaunchKernelGGL(mmr_simmat_batch_kernel<12>, grid, dim3(256), 0, s, args_dev);
+    else if (jl <= 16) hipLaunchKernelGGL(mmr_simmat_batch_kernel<16>, grid, dim3(256), 0, s, args_dev);
+    else hipLaunchKernelGGL(mmr_simmat_batch_kernel<0>, grid, dim3(256), 0, s, args_dev);
+    hipLaunchKernelGGL(mmr_select_batch_kernel, dim3(1, y), dim3(1024), 0, s, args_dev);
+    RAG_HIP_CHECK(hipGetLastError());
+    return RAG_OK;
 }
 
 }  // namespace rag
@@ -1225,24 +1305,45 @@ int rag_index_hybrid_mmr_batch_device(rag_index_t* h, int64_t nq, const float* q
     const HybridPlan pl = hybrid_plan(h, topn, (int)nb, fuse_limit, max_results);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc = ws_acquire(h, s)) return rc;
-    // the tails of different queries are independent and small (a few workgroups each): they are dealt over side streams
-    // between a fork and a join on the caller's stream (RAG_HYBRID_TAIL_STREAMS=1: all on the caller's stream)
-    static const int ns_env = env_int_m("RAG_HYBRID_TAIL_STREAMS", rag_index::kTailStreams);
-    const int NS = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(ns_env, (int)rag_index::kTailStreams), nq));
-    if (NS > 1) {
-        if (!h->tail_fork) RAG_HIP_CHECK(hipEventCreateWithFlags(&h->tail_fork, hipEventDisableTiming));
-        for (int j = 0; j < NS; ++j) {
-            if (!h->tail_stream[j]) RAG_HIP_CHECK(hipStreamCreateWithFlags(&h->tail_stream[j], hipStreamNonBlocking));
-            if (!h->tail_join[j]) RAG_HIP_CHECK(hipEventCreateWithFlags(&h->tail_join[j], hipEventDisableTiming));
-        }
-    }
-    // [fusion / MMR buffers, one set per stream | scores of every query's semantic hits | their row positions]
-    const size_t db = al256((size_t)nq * topn * sizeof(float)), ib = al256((size_t)nq * topn * sizeof(long long));
+    // fusion and MMR run for a chunk of queries at a time (one launch per stage, blockIdx.y = query), every query of a chunk
+    // with its own set of the plan's buffers; the per-query arguments are built here and copied to the device up front
+    // (they hold addresses only, nothing the search produces)
     const size_t tail_bytes = al256(pl.total);
-    if (int rc = h->ws3.ensure((size_t)NS * tail_bytes + db + ib)) return rc;
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(nq, 512), (int64_t)(((size_t)2 << 30) / tail_bytes)));
+    const size_t ab = al256((size_t)nq * sizeof(TailArgs));
+    const size_t db = al256((size_t)nq * topn * sizeof(float)), ib = al256((size_t)nq * topn * sizeof(long long));
+    if (int rc = h->ws3.ensure((size_t)chunk * tail_bytes + ab + db + ib)) return rc;
     char* w = static_cast<char*>(h->ws3.ptr);
-    float* Dall = reinterpret_cast<float*>(w + (size_t)NS * tail_bytes);
-    long long* Rall = reinterpret_cast<long long*>(w + (size_t)NS * tail_bytes + db);
+    TailArgs* args_dev = reinterpret_cast<TailArgs*>(w + (size_t)chunk * tail_bytes);
+    float* Dall = reinterpret_cast<float*>(w + (size_t)chunk * tail_bytes + ab);
+    long long* Rall = reinterpret_cast<long long*>(w + (size_t)chunk * tail_bytes + ab + db);
+    const int M = pl.M;
+    {
+        // pinned staging that belongs to the index; the event says when the last copy out of it has been made
+        if (h->tail_args_cap < (size_t)nq * sizeof(TailArgs)) {
+            if (h->tail_args_event) RAG_HIP_CHECK(hipEventSynchronize(h->tail_args_event));
+            if (h->tail_args_host) RAG_HIP_CHECK(hipHostFree(h->tail_args_host));
+            h->tail_args_host = nullptr;
+            h->tail_args_cap = 0;
+            RAG_HIP_CHECK(hipHostMalloc(&h->tail_args_host, (size_t)nq * sizeof(TailArgs), hipHostMallocDefault));
+            h->tail_args_cap = (size_t)nq * sizeof(TailArgs);
+        }
+        if (!h->tail_args_event) RAG_HIP_CHECK(hipEventCreateWithFlags(&h->tail_args_event, hipEventDisableTiming));
+        else RAG_HIP_CHECK(hipEventSynchronize(h->tail_args_event));
+        TailArgs* host = static_cast<TailArgs*>(h->tail_args_host);
+        for (int64_t i = 0; i < nq; ++i) {
+            rag_hybrid_out_t dst = {};
+            dst.ids = ids_dev + (size_t)i * M;
+            dst.scores = scores_dev + (size_t)i * M;
+            dst.n_out = n_out_dev + i;
+            host[i] = hybrid_tail_args(h, pl, w + (size_t)(i % chunk) * tail_bytes, Dall + (size_t)i * topn, Rall + (size_t)i * topn,
+                                       nb > 0 ? reinterpret_cast<const long long*>(bm25_rows_dev) + (size_t)i * nb : nullptr,
+                                       nb > 0 ? bm25_scores_dev + (size_t)i * nb : nullptr, w_sem, w_bm25, mmr_lambda, mmr_threshold,
+                                       mmr_metric, dst);
+        }
+        RAG_HIP_CHECK(hipMemcpyAsync(args_dev, host, (size_t)nq * sizeof(TailArgs), hipMemcpyHostToDevice, s));
+        RAG_HIP_CHECK(hipEventRecord(h->tail_args_event, s));
+    }
     // 1. the semantic top-N of all queries as ONE search.  It leaves row positions (the id table and base are set aside for
     //    it: the index is locked and they are read when a launch is built); ids are named when the hits are final
     long long* const ids = h->ids_dev;
@@ -1253,33 +1354,11 @@ int rag_index_hybrid_mmr_batch_device(rag_index_t* h, int64_t nq, const float* q
     h->ids_dev = ids;
     h->id_base = base;
     if (rc) return rc;
-    // 2. fusion and MMR query by query behind it on the same stream (each a few small launches; the buffers are reused in stream order)
-    const int M = pl.M;
+    // 2. fusion and MMR behind it on the same stream, a chunk of queries per launch
     RAG_HIP_CHECK(hipMemsetAsync(ids_dev, 0xFF, (size_t)nq * M * sizeof(int64_t), s));        // slots past a query's count: -1
     RAG_HIP_CHECK(hipMemsetAsync(n_out_dev, 0, (size_t)nq * sizeof(int32_t), s));
-    if (NS > 1) {
-        RAG_HIP_CHECK(hipEventRecord(h->tail_fork, s));
-        for (int j = 0; j < NS; ++j) RAG_HIP_CHECK(hipStreamWaitEvent(h->tail_stream[j], h->tail_fork, 0));
-    }
-    int rc2 = RAG_OK;
-    for (int64_t i = 0; i < nq && rc2 == RAG_OK; ++i) {
-        const int j = (int)(i % NS);
-        rag_hybrid_out_t dst = {};
-        dst.ids = ids_dev + (size_t)i * M;
-        dst.scores = scores_dev + (size_t)i * M;
-        dst.n_out = n_out_dev + i;
-        rc2 = hybrid_tail(h, pl, w + (size_t)j * tail_bytes, Dall + (size_t)i * topn, Rall + (size_t)i * topn,
-                          nb > 0 ? reinterpret_cast<const long long*>(bm25_rows_dev) + (size_t)i * nb : nullptr,
-                          nb > 0 ? bm25_scores_dev + (size_t)i * nb : nullptr, w_sem, w_bm25, mmr_lambda, mmr_threshold, mmr_metric,
-                          dst, NS > 1 ? h->tail_stream[j] : s);
-    }
-    if (NS > 1) {         // the join is enqueued whatever happened above: the caller's stream must not run ahead of the side streams
-        for (int j = 0; j < NS; ++j) {
-            RAG_HIP_CHECK(hipEventRecord(h->tail_join[j], h->tail_stream[j]));
-            RAG_HIP_CHECK(hipStreamWaitEvent(s, h->tail_join[j], 0));
-        }
-    }
-    if (rc2) return rc2;
+    for (int64_t q0 = 0; q0 < nq; q0 += chunk)
+        if (int rc2 = hybrid_tail_batch(h, pl, args_dev + q0, (int)std::min<int64_t>(chunk, nq - q0), s)) return rc2;
     return ws_release(h, s);
 }
 

@@ -97,12 +97,11 @@ struct rag_index {
     rag::Workspace ws3;             // search -> fusion -> MMR pipeline: candidate lists, fp64 rows, pair matrix
     long long* merge_rows_out = nullptr;   // while set, the final merge of a search also writes every hit's row position here
     hipStream_t stream = nullptr;   // used by the host-pointer entry points
-    // side streams of the batched search -> fusion -> MMR call (its per-query tails run on them between a fork
-    // and a join on the caller's stream), created on first use
-    static constexpr int kTailStreams = 4;
-    hipStream_t tail_stream[kTailStreams] = {};
-    hipEvent_t tail_fork = nullptr;
-    hipEvent_t tail_join[kTailStreams] = {};
+    // pinned staging of the batched search -> fusion -> MMR call (its per-query kernel arguments on their way to the
+    // device) and the event behind the last copy out of it
+    void* tail_args_host = nullptr;
+    size_t tail_args_cap = 0;
+    hipEvent_t tail_args_event = nullptr;
     hipEvent_t ws_event = nullptr;  // end of the last work that used ws / ws2
     hipStream_t ws_stream = nullptr;
     bool ws_pending = false;
