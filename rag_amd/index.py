@@ -504,9 +504,20 @@ def hybrid_mmr_batch(index: "DeviceIndex", q, topn: int, bm25_rows, bm25_scores,
     fusion and MMR per query behind it on torch's current stream (rag_index_hybrid_mmr_batch_device).
 
     ``q``: CUDA float32 ``[nq, dim]``; ``bm25_rows`` / ``bm25_scores``: CUDA ``[nq, nb]`` (int64 row positions, -1 pads a
-    shorter list; float64 scores).  Returns CUDA tensors ``(ids [nq, M] int64, -1 past a query's count; scores [nq, M]
+    shorter list; float64 scores); numpy arrays of the same shapes are staged to the device and answered with numpy arrays.
+    Returns CUDA tensors ``(ids [nq, M] int64, -1 past a query's count; scores [nq, M]
     float64, the fused scores; n_out [nq] int32)`` with ``M = min(max_results, fuse_limit, topn + nb)``; nothing is synchronised."""
     import torch
+    if isinstance(q, np.ndarray):
+        # host arrays: staged to the index's device, answered there, copied back (one synchronisation at the end)
+        dev = torch.device("cuda", index.device)
+        mask_t = None if row_mask is None else torch.from_numpy(np.ascontiguousarray(row_mask, dtype=np.uint8)).to(dev)
+        out = hybrid_mmr_batch(index, torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32)).to(dev), topn,
+                               torch.from_numpy(np.ascontiguousarray(bm25_rows, dtype=np.int64)).to(dev),
+                               torch.from_numpy(np.ascontiguousarray(bm25_scores, dtype=np.float64)).to(dev), fuse_limit=fuse_limit,
+                               max_results=max_results, semantic_weight=semantic_weight, bm25_weight=bm25_weight, mmr_lambda=mmr_lambda,
+                               mmr_threshold=mmr_threshold, mmr_metric=mmr_metric, min_score=min_score, nprobe=nprobe, row_mask=mask_t)
+        return tuple(t.cpu().numpy() for t in out)
     if not _is_torch_cuda(q) or q.dtype != torch.float32 or q.dim() != 2 or q.shape[1] != index.dim:
         raise ValueError(f"expected a CUDA float32 [nq, {index.dim}] tensor")
     q = q.contiguous()

@@ -225,6 +225,10 @@ def _check_batch(idx, X, Q, topn, bm_rows, bm_scores, to_rows, to_id, *, max_res
         assert gi[i, :gn[i]].tolist() == want_ids, (idx.kind, nq, topn, i)
         assert np.array_equal(gs[i, :gn[i]], np.array([f_scores[p] for p in picked])), (idx.kind, nq, topn, i)
         assert np.all(gi[i, gn[i]:] == -1)
+    if nq <= 12:           # host arrays in, host arrays out: the same answer
+        from rag_amd.index import hybrid_mmr_batch as hb
+        hi, hs, hn = hb(idx, Q, topn, bm_rows, bm_scores, max_results=max_results, mmr_lambda=lam, mmr_threshold=thr, mmr_metric=metric, **kw)
+        assert np.array_equal(hi, gi) and np.array_equal(hn, gn) and all(np.array_equal(hs[i, :gn[i]], gs[i, :gn[i]]) for i in range(nq))
 
 
 def test_batched_pipeline_equals_the_oracle_per_query():
