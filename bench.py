@@ -435,17 +435,25 @@ def leg_small_corpus(torch, args, device, rows=100_000, dim=384, k=10):
     Q = make_queries(torch, 4096, dim, device)
     idx = DeviceIndex(dim, metric="ip", device=device.index)
     idx.adopt(X)
-    idx.profile(True)
+    # results go to buffers the caller owns, as the C ABI has it.  Two loops: the timed one without the event pairs around the
+    # scan kernel (two timed event records weigh several microseconds on a 40 us search), then the same searches with them
+    # for the kernel time
+    Dout = torch.empty((1, k), dtype=torch.float32, device=device)
+    Iout = torch.empty((1, k), dtype=torch.int64, device=device)
     for i in range(10):
-        idx.search(Q[i:i + 1], k)
+        idx.search_into(Q[i:i + 1], k, Dout.data_ptr(), Iout.data_ptr())
     torch.cuda.synchronize(device)
-    idx.profile_read(reset=True)
     nsteps = 200
     t0 = time.perf_counter()
     for i in range(nsteps):
-        idx.search(Q[i:i + 1], k)
+        idx.search_into(Q[i:i + 1], k, Dout.data_ptr(), Iout.data_ptr())
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
+    idx.profile(True)
+    idx.profile_read(reset=True)
+    for i in range(nsteps):
+        idx.search_into(Q[i:i + 1], k, Dout.data_ptr(), Iout.data_ptr())
+    torch.cuda.synchronize(device)
     kms, launches = idx.profile_read(reset=True)
     scan_us = kms / max(launches, 1) * 1e3
     gbs = rows * dim * 4 / (scan_us * 1e-6) / 1e9 if launches else 0.0
@@ -510,17 +518,25 @@ def leg_ivf_share(torch, args, device, rows=12_500_000, dim=1024, nlist=16384, n
     out = {"workload": f"IVF-flat, {rows}x{dim} fp32 (one GPU's share of 100M), nlist {nlist}, nprobe {nprobe}, top-{k}",
            "add_assign_s": t_add, "first_search_pack_s": t_pack}
     per_query = nprobe * (rows / nlist) * dim * 4
-    ivf.profile(True)
     for nq, nsteps in ((1, 100), (4096, 3)):
+        ivf.profile(False)
         ivf.search(Q[:nq], k, nprobe=nprobe)
         torch.cuda.synchronize(device)
-        ivf.profile_read(reset=True)
+        Dout = torch.empty((nq, k), dtype=torch.float32, device=device)      # caller-owned result buffers, as the C ABI has it
+        Iout = torch.empty((nq, k), dtype=torch.int64, device=device)
+
+        def run():
+            for i in range(nsteps):
+                j = i % 64 if nq == 1 else 0
+                ivf.search_into(Q[j:j + nq], k, Dout.data_ptr(), Iout.data_ptr(), nprobe=nprobe)
+            torch.cuda.synchronize(device)
+
         t0 = time.perf_counter()
-        for i in range(nsteps):
-            j = i % 64 if nq == 1 else 0
-            ivf.search(Q[j:j + nq], k, nprobe=nprobe)
-        torch.cuda.synchronize(device)
+        run()                                           # timed without the event pairs around the list scan ...
         dt = time.perf_counter() - t0
+        ivf.profile(True)
+        ivf.profile_read(reset=True)
+        run()                                           # ... which this second pass records for the kernel time
         kms, launches = ivf.profile_read(reset=True)
         scan_ms = kms / max(launches, 1)
         leg = {"value": nq * nsteps / dt, "unit": "queries/sec", "batch": nq, "ms_per_step": dt / nsteps * 1e3,
