@@ -85,8 +85,10 @@ __host__ __device__ constexpr int gemm_trig_max(int RT, int QT) { return QT >= 1
 // within a factor of ~3 of the current one; the sort of a compaction then covers 64 or 128 keys.
 // The bf16 pass carries every key within the margin of the k-th best across a compaction (a few times k
 // on unstructured data), so it triggers later.
+// k above 64 (the 256 x 256 shape only, up to GEMM_BIG_MAX_K): the trigger is the buffer's whole first half, 256 keys, which has
+// to stay well above k -- a buffer cut to k keys that is past its trigger again after a push would compact at every tile.
 __host__ __device__ constexpr int gemm_trig(int RT, int QT, int k, bool b16 = false) {
-    return QT >= 128 ? (b16 ? (k <= 16 ? 128 : RT) : (k <= 16 ? 32 : (k <= 32 ? 64 : 128)))
+    return QT >= 128 ? (b16 ? (k <= 16 ? 128 : RT) : (k <= 16 ? 32 : (k <= 32 ? 64 : (k <= 64 ? 128 : RT))))
                      : (b16 ? 128 : (k <= 32 ? 64 : 128));
 }
 __host__ __device__ constexpr int gemm_capq(int RT, int QT) { return gemm_trig_max(RT, QT) + RT; }
@@ -812,9 +814,19 @@ static bool narrow_bf16_ok(const rag_index* h, int k) {
 }
 
 // from 5 queries; with the bf16 first pass in the narrow shape from 2 (half a corpus pass instead of a whole one)
+// The 256 x 256 shape carries up to 200 keys per query (its candidate buffers hold 512, the trigger sits at 256): batches that
+// take that shape keep their selection in the kernel up to k = 200 -- the reference's largest request, limit * 2 with limit <= 100 --
+// instead of sending a score matrix through HBM -- from 2048 queries, where a workgroup's row range is long enough for the
+// thresholds to settle (10M x 768, k = 200: 4096 queries 589 ms by the segment walk, 514 ms here; 512 queries 78.5 against 84.1,
+// 1024 queries the same either way).
+constexpr int GEMM_BIG_MAX_K = 200;
+static bool gemm_big_shape(const rag_index* h, long long nq);
 bool gemm_topk_supported(const rag_index* h, long long nq, int k) {
     static const int min_nq = env_int_g("RAG_GEMM_MIN_NQ", 5);
-    if (!(h->kind == RAG_KIND_FLAT && k <= GEMM_MAX_K && (h->ld % GK) == 0 && h->n >= 1)) return false;
+    static const int big_max_k = std::min(GEMM_BIG_MAX_K, env_int_g("RAG_GEMM_BIG_MAX_K", GEMM_BIG_MAX_K));      // 64 switches it off
+    if (!(h->kind == RAG_KIND_FLAT && (h->ld % GK) == 0 && h->n >= 1)) return false;
+    static const int big_k_min_nq = env_int_g("RAG_GEMM_BIG_K_MIN_NQ", 2048);
+    if (k > GEMM_MAX_K && !(k <= big_max_k && nq >= big_k_min_nq && !h->prefilter && gemm_big_shape(h, nq))) return false;
     return nq >= min_nq || (nq >= 2 && narrow_bf16_ok(h, k));
 }
 
@@ -884,6 +896,15 @@ static GemmPlan gemm_plan(const rag_index* h, long long nq, int k) {
     p.margin_bytes = p.pref ? (((size_t)nq * sizeof(float) + 255) & ~(size_t)255) : 0;
     p.part16_bytes = p.pref ? (size_t)nq * p.S * pref_outc(p.S, p.QT, k) * sizeof(u64) : 0;
     return p;
+}
+
+// does a batch of nq queries take the 256 x 256 shape (what gemm_plan decides for the fp32 path without the first pass)
+static bool gemm_big_shape(const rag_index* h, long long nq) {
+    static const int force_qt = env_int_g("RAG_GEMM_QT", 0);
+    static const int big_min_nq = env_int_g("RAG_GEMM_BIG_MIN_NQ", 1024);
+    if (force_qt) return force_qt == 256;
+    const bool same_pad = nq > 128 && h->n >= (1 << 20) && (nq + 255) / 256 * 256 == (nq + 127) / 128 * 128;
+    return nq >= big_min_nq || same_pad;
 }
 
 // bytes of workspace the gemm path needs after the padded queries

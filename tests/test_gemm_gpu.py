@@ -141,7 +141,9 @@ def test_scores_path_matches_oracle(n, d, nq, k):
 
 
 @pytest.mark.parametrize("n,d,nq,k", [(100_000, 128, 40, 100), (65_537, 64, 300, 200), (40_000, 96, 9, 1024), (200_000, 32, 1100, 65),
-                                       (32_769, 256, 8, 100), (1_500, 64, 20, 300), (98_304, 384, 600, 128)])
+                                       (32_769, 256, 8, 100), (1_500, 64, 20, 300), (98_304, 384, 600, 128),
+                                       # the selecting kernel's 256 x 256 shape up to k = 200 (2048+ queries), the segment walk otherwise
+                                       (120_000, 64, 2048, 200), (60_000, 128, 2500, 100), (50_000, 96, 2100, 201), (90_000, 32, 1024, 150)])
 def test_segments_path_matches_oracle(n, d, nq, k):
     """k above 64 with 8 or more queries: the corpus is walked in segments of 32768 rows (score matrix on the matrix
     cores, one selection workgroup per query and segment) and the per-segment lists are merged (path "gemm-segments").
@@ -158,14 +160,16 @@ def test_segments_path_matches_oracle(n, d, nq, k):
     idx = DeviceIndex(d, metric="ip")
     idx.add(X[: n // 3], ids=ids[: n // 3])
     idx.add(X[n // 3:], ids=ids[n // 3:])
+    from paths import flat_fp32_path
+    want_path = flat_fp32_path(n, d, nq, k)          # 2048+ queries up to k = 200 stay in the selecting kernel's 256 x 256 shape
     D, I = idx.search(Q, k)
-    assert idx.last_path == "gemm-segments"
+    assert idx.last_path == want_path
     _check(D, I, X, Q, k, ids=ids)
     if n > 40_000:
         assert I[0, 0] == ids[7] and I[0, 1] == ids[32_768 + 5] and D[0, 0] == D[0, 1]
     mask = (rng.uniform(size=n) < 0.3).astype(np.uint8)
     D, I = idx.search(Q, k, row_mask=mask, min_score=0.1)        # most queries end with fewer than k hits
-    assert idx.last_path == "gemm-segments"
+    assert idx.last_path == want_path
     _check(D, I, X, Q, k, ids=ids, row_mask=mask, min_score=0.1)
     idx.set_active(np.arange(0, n, 3), False)
     alive = np.ones(n, np.uint8)
