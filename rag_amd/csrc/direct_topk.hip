@@ -95,12 +95,23 @@ struct SelectArgs {
     float* D;                    // [nq][k]
     long long* I;                // [nq][k]
     long long* rows_out;         // nullptr or [nq][k]: row position of every hit (-1 where I is -1)
+    // a query's score row may hold several segments of n rows each (the last one shorter): workgroup b then serves
+    // query b / segs, segment b % segs, and segment g of query q writes its list at g * out_stride + q * k
+    int segs;                    // 1: one segment per query
+    long long n_row;             // scores per query row (n when segs == 1)
+    long long out_stride;        // hits between the lists of consecutive segments (0 when segs == 1)
 };
 
 template <int SEL_REG>                  // scores per thread: n <= SEL_REG * 1024
 __global__ __launch_bounds__(1024) void direct_select_kernel(SelectArgs p) {
-    const int n = p.n, k = p.k;
-    const float* scores = p.scores;
+    const int k = p.k;
+    const int qi = (int)(blockIdx.x / (unsigned)p.segs), sg = (int)(blockIdx.x % (unsigned)p.segs);
+    const long long seg_lo = (long long)sg * p.n;
+    const int n = (int)(p.n_row - seg_lo < p.n ? p.n_row - seg_lo : p.n);
+    const uint8_t* mask = p.mask ? p.mask + seg_lo : nullptr;
+    const long long* row_ids = p.row_ids ? p.row_ids + seg_lo : nullptr;
+    const long long id_base = p.id_base + seg_lo;
+    const size_t obase = (size_t)sg * p.out_stride + (size_t)qi * k;
     float* D = p.D;
     long long* I = p.I;
 
@@ -109,7 +120,7 @@ __global__ __launch_bounds__(1024) void direct_select_kernel(SelectArgs p) {
     __shared__ u64 s_lo, s_hi, s_bound;
     __shared__ int s_cnt, s_above, s_done;
     const int tid = threadIdx.x, lane = tid & 63;
-    const float* sc = scores + (size_t)blockIdx.x * n;
+    const float* sc = p.scores + (size_t)qi * p.n_row + seg_lo;
     if (tid == 0) { s_lo = ~0ull; s_hi = 0ull; }
     __syncthreads();
     u64 head = KEY_EMPTY;                                          // this thread's best key
@@ -122,10 +133,10 @@ __global__ __launch_bounds__(1024) void direct_select_kernel(SelectArgs p) {
         for (int u0 = 0; u0 < SEL_REG; u0 += 8) {                  // eight loads per memory latency
 #pragma unroll
             for (int u = u0; u < u0 + 8; ++u) v[u] = tid + u * 1024 < n ? sc[tid + u * 1024] : NAN;
-            if (p.mask) {
+            if (mask) {
                 unsigned char mk[8];
 #pragma unroll
-                for (int u = u0; u < u0 + 8; ++u) mk[u - u0] = tid + u * 1024 < n ? p.mask[tid + u * 1024] : 0;
+                for (int u = u0; u < u0 + 8; ++u) mk[u - u0] = tid + u * 1024 < n ? mask[tid + u * 1024] : 0;
 #pragma unroll
                 for (int u = u0; u < u0 + 8; ++u) v[u] = mk[u - u0] ? v[u] : NAN;
             }
@@ -224,9 +235,9 @@ __global__ __launch_bounds__(1024) void direct_select_kernel(SelectArgs p) {
         cnum = 0;
     }
     for (int j = tid; j < k; j += 1024) {                     // slots that stay empty
-        D[(size_t)blockIdx.x * k + j] = -FLT_MAX;
-        I[(size_t)blockIdx.x * k + j] = -1;
-        if (p.rows_out) p.rows_out[(size_t)blockIdx.x * k + j] = -1;
+        D[obase + j] = -FLT_MAX;
+        I[obase + j] = -1;
+        if (p.rows_out) p.rows_out[obase + j] = -1;
     }
     __syncthreads();
     for (int i = tid; i < cnum; i += 1024) {
@@ -237,9 +248,9 @@ __global__ __launch_bounds__(1024) void direct_select_kernel(SelectArgs p) {
         const float sv = key_score(mine);
         if (above < k && sv >= p.min_score) {
             const long long row = (long long)key_row(mine);
-            D[(size_t)blockIdx.x * k + above] = sv;
-            I[(size_t)blockIdx.x * k + above] = p.row_ids ? p.row_ids[row] : p.id_base + row;
-            if (p.rows_out) p.rows_out[(size_t)blockIdx.x * k + above] = row;
+            D[obase + above] = sv;
+            I[obase + above] = row_ids ? row_ids[row] : id_base + row;
+            if (p.rows_out) p.rows_out[obase + above] = seg_lo + row;
         }
     }
 }
@@ -248,6 +259,8 @@ int direct_select_launch(rag_index* h, long long nq, int k, float min_score, con
                          long long* I, hipStream_t s);
 int direct_select_rows(long long nq, int n, int k, float min_score, const uint8_t* mask, const long long* row_ids, long long id_base,
                        long long* rows_out, const float* scores, float* D, long long* I, hipStream_t s);
+int direct_select_segments(long long nq, long long n_row, int k, float min_score, const uint8_t* mask, const long long* row_ids,
+                           long long id_base, const float* scores, float* D, long long* I, long long out_stride, hipStream_t s);
 
 bool direct_topk_supported(const rag_index* h, long long nq, int k) {
     static const int on = getenv("RAG_DIRECT_TOPK") ? atoi(getenv("RAG_DIRECT_TOPK")) : 1;          // measurement knob
@@ -297,9 +310,38 @@ int direct_select_rows(long long nq, int n, int k, float min_score, const uint8_
     p.D = D;
     p.I = I;
     p.rows_out = rows_out;
+    p.segs = 1;
+    p.n_row = n;
+    p.out_stride = 0;
     if (n <= 8 * 1024) hipLaunchKernelGGL(direct_select_kernel<8>, dim3((unsigned)nq), dim3(1024), 0, s, p);
     else if (n <= 16 * 1024) hipLaunchKernelGGL(direct_select_kernel<16>, dim3((unsigned)nq), dim3(1024), 0, s, p);
     else hipLaunchKernelGGL(direct_select_kernel<SEL_REG_MAX>, dim3((unsigned)nq), dim3(1024), 0, s, p);
+    RAG_HIP_CHECK(hipGetLastError());
+    return RAG_OK;
+}
+
+// a score row of n_row scores per query, taken as segments of 32768 rows (the last one shorter): one workgroup per
+// (query, segment); the list of segment g and query q starts at hit g * out_stride + q * k of D and I
+int direct_select_segments(long long nq, long long n_row, int k, float min_score, const uint8_t* mask, const long long* row_ids,
+                           long long id_base, const float* scores, float* D, long long* I, long long out_stride, hipStream_t s) {
+    const long long seg = (long long)SEL_REG_MAX * 1024;
+    const long long segs = (n_row + seg - 1) / seg;
+    if (segs < 1 || nq * segs > 0x7fffffffLL) return fail(RAG_ERR_INVALID, "internal: segment selection grid");
+    SelectArgs p = {};
+    p.scores = scores;
+    p.n = (int)seg;
+    p.k = k;
+    p.mask = mask;
+    p.min_score = min_score;
+    p.row_ids = row_ids;
+    p.id_base = id_base;
+    p.D = D;
+    p.I = I;
+    p.rows_out = nullptr;
+    p.segs = (int)segs;
+    p.n_row = n_row;
+    p.out_stride = out_stride;
+    hipLaunchKernelGGL(direct_select_kernel<SEL_REG_MAX>, dim3((unsigned)(nq * segs)), dim3(1024), 0, s, p);
     RAG_HIP_CHECK(hipGetLastError());
     return RAG_OK;
 }

@@ -1141,7 +1141,7 @@ int gemm_scores_search(rag_index* h, long long nq, const float* qbuf, int k, flo
 }
 
 // ---------------------------------------------------------------------------------------------
-// k above what the selecting kernel carries (64), 8 or more queries, any corpus: the in-kernel candidate buffers do not
+// k above what the selecting kernel carries (64), 2 or more queries, any corpus: the in-kernel candidate buffers do not
 // scale to hundreds of keys per query, and the fallback used to be one full scan of the corpus PER QUERY (64 queries,
 // k = 100, 10M rows: 64 x 4.6 ms).  Path "gemm-segments" walks the corpus in segments of 32768 rows: the score-writing
 // kernel above fills the [queries x segment] score matrix, direct_select_kernel leaves every query's k best of the
@@ -1164,22 +1164,29 @@ static long long seg_query_chunk(long long nseg, int k) {
 }
 
 bool gemm_segments_supported(const rag_index* h, long long nq, int k) {
-    static const int min_nq = env_int_g("RAG_GEMM_SEGMENTS_MIN_NQ", 8);         // 0 switches the path off (measurement knob)
+    static const int min_nq = env_int_g("RAG_GEMM_SEGMENTS_MIN_NQ", 2);         // 0 switches the path off (measurement knob)
     return min_nq > 0 && h->kind == RAG_KIND_FLAT && !h->prefilter && (h->ld % GK) == 0 && h->n >= 1024 && nq >= min_nq &&
            k > GEMM_MAX_K && k <= 1024 && h->n <= ((long long)1 << 31) - SCORES_MAX_ROWS;
 }
 
+// Segments go to the kernels in groups: one score-writing launch fills the rows of `group` consecutive segments
+// ([queries][group * 32768] scores) and one selection launch runs a workgroup per (query, segment) of the group.  A
+// small chunk of queries takes large groups, so that both launches have a few hundred workgroups, and the narrow
+// query shapes (256 x 32 up to 32 queries, 128 x 64 up to 64), which read the corpus once without multiplying padding
+// columns; from 1024 queries a segment alone fills the chip.
 struct SegPlan {
-    long long nseg, qc;
+    long long nseg, qc, group;
     size_t scores_bytes, d_bytes, i_bytes, keys_bytes;
 };
 static SegPlan seg_plan(const rag_index* h, long long nq, int k) {
+    static const long long max_group = std::max(1, env_int_g("RAG_GEMM_SEGMENTS_GROUP", 32));        // measurement knob
     SegPlan p;
     p.nseg = (h->n + SCORES_MAX_ROWS - 1) / SCORES_MAX_ROWS;
     p.qc = std::min<long long>(nq, seg_query_chunk(p.nseg, k));
-    const long long seg_rows = std::min<long long>(h->n, SCORES_MAX_ROWS);
+    p.group = std::max<long long>(1, std::min<long long>(std::min<long long>(max_group, p.nseg), 1024 / p.qc));
+    const long long group_rows = std::min<long long>(h->n, p.group * SCORES_MAX_ROWS);
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    p.scores_bytes = al((size_t)p.qc * seg_rows * sizeof(float));
+    p.scores_bytes = al((size_t)p.qc * group_rows * sizeof(float));
     p.d_bytes = al((size_t)p.nseg * p.qc * k * sizeof(float));
     p.i_bytes = al((size_t)p.nseg * p.qc * k * sizeof(long long));
     p.keys_bytes = al((size_t)p.nseg * p.qc * k * sizeof(u64));
@@ -1189,6 +1196,9 @@ size_t gemm_segments_workspace(const rag_index* h, long long nq, int k) {
     const SegPlan p = seg_plan(h, nq, k);
     return p.scores_bytes + p.d_bytes + p.i_bytes + p.keys_bytes;
 }
+
+int direct_select_segments(long long nq, long long n_row, int k, float min_score, const uint8_t* mask, const long long* row_ids,
+                           long long id_base, const float* scores, float* D, long long* I, long long out_stride, hipStream_t s);   // direct_topk.hip
 
 int gemm_segments_search(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask, float* D,
                          long long* I, hipStream_t s) {
@@ -1203,30 +1213,36 @@ int gemm_segments_search(rag_index* h, long long nq, const float* qbuf, int k, f
     if (int rc = profile_begin(h, s)) return rc;
     for (long long q0 = 0; q0 < nq; q0 += p.qc) {
         const long long qc = std::min(p.qc, nq - q0);
-        const bool big = qc >= 512;                   // the 256 x 256 shape from 512 queries, 128 x 128 below
-        const int QT = big ? 256 : 128;
-        for (long long sg = 0; sg < p.nseg; ++sg) {
-            const long long lo = sg * SCORES_MAX_ROWS, rows = std::min<long long>(SCORES_MAX_ROWS, h->n - lo);
+        // the last chunk of a batch may be shorter than the chunk the group was planned for: its shape follows its own size
+        const int QT = qc >= 512 ? 256 : qc > 64 ? 128 : qc > 32 ? 64 : 32;
+        const int RT = QT == 32 ? 256 : QT == 64 ? 128 : QT;
+        for (long long sg = 0; sg < p.nseg; sg += p.group) {
+            const long long lo = sg * SCORES_MAX_ROWS, rows = std::min<long long>(p.group * SCORES_MAX_ROWS, h->n - lo);
             GemmArgs a = {};
             a.X = h->X + (size_t)lo * h->ld;
             a.Q = qbuf + (size_t)q0 * h->ld;
             a.n = rows;
-            a.ntiles = (rows + QT - 1) / QT;
+            a.ntiles = (rows + RT - 1) / RT;
             a.nq = (int)qc;
             a.ld = h->ld;
             a.k = k;
             a.nqb = (int)((qc + QT - 1) / QT);
             a.nqb_pad = a.nqb;
-            a.S = (int)std::max<long long>(1, std::min<long long>(a.ntiles, ((big ? 256 : 512) + a.nqb_pad - 1) / a.nqb_pad));
+            a.S = (int)std::max<long long>(1, std::min<long long>(a.ntiles, ((QT == 256 ? 256 : 512) + a.nqb_pad - 1) / a.nqb_pad));
             a.gq = 0;
             a.outc = k;
-            a.trig = gemm_trig(QT, QT, GEMM_MAX_K);
+            a.trig = gemm_trig(RT, QT, GEMM_MAX_K);
             a.scores = scores;
             const int grid = a.nqb_pad * a.S;
-            if (int rc = big ? launch_gemm_store<256, 256, 8>(a, grid, h->device, s) : launch_gemm_store<128, 128, 4>(a, grid, h->device, s)) return rc;
-            if (int rc = direct_select_rows(qc, (int)rows, k, min_score, mask ? mask + lo : nullptr, h->ids_dev ? h->ids_dev + lo : nullptr,
-                                            h->id_base + lo, nullptr, scores, Dseg + (size_t)sg * qc * k, Iseg + (size_t)sg * qc * k, s))
-                return rc;
+            int rc;
+            if (QT == 256) rc = launch_gemm_store<256, 256, 8>(a, grid, h->device, s);
+            else if (QT == 128) rc = launch_gemm_store<128, 128, 4>(a, grid, h->device, s);
+            else if (QT == 64) rc = launch_gemm_store<128, 64, 4>(a, grid, h->device, s);
+            else rc = launch_gemm_store<256, 32, 4>(a, grid, h->device, s);
+            if (rc) return rc;
+            if (int rc2 = direct_select_segments(qc, rows, k, min_score, mask ? mask + lo : nullptr, h->ids_dev ? h->ids_dev + lo : nullptr,
+                                                 h->id_base + lo, scores, Dseg + (size_t)sg * qc * k, Iseg + (size_t)sg * qc * k, qc * k, s))
+                return rc2;
         }
         if (int rc = merge_lists_device((int)p.nseg, qc, k, Dseg, qc * k, Iseg, qc * k, D + (size_t)q0 * k, I + (size_t)q0 * k, keys, s)) return rc;
     }

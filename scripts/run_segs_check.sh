@@ -1,0 +1,13 @@
+#!/bin/bash
+# the segment walk (k above 64 in a batch): its parity tests, then ms per batch at 10M x 768 and on small corpora with the walk on and off
+set -e
+mkdir -p gpurun_out/segs
+timeout -k 10 900 python3 -u -m pytest tests -x -q -m gpu --timeout 120 --timeout-method thread > gpurun_out/segs/tests.txt 2>&1
+tail -3 gpurun_out/segs/tests.txt
+for shape in "100000 384" "1000000 768"; do
+  set -- $shape
+  ROWS=$1 DIM=$2 CASES=2:100,5:100,7:200,8:100 timeout -k 10 200 python3 -u scripts/bench_large_k.py > gpurun_out/segs/small_$1.txt 2>&1
+  cat gpurun_out/segs/small_$1.txt
+  ROWS=$1 DIM=$2 RAG_GEMM_SEGMENTS_MIN_NQ=0 CASES=2:100,5:100,7:200,8:100 timeout -k 10 200 python3 -u scripts/bench_large_k.py > gpurun_out/segs/small_$1_scan.txt 2>&1
+  cat gpurun_out/segs/small_$1_scan.txt
+done

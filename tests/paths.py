@@ -18,6 +18,6 @@ def flat_fp32_path(n, d, nq, k):
     big_shape = nq >= 1024 or (nq > 128 and n >= 1 << 20 and -(-nq // 256) * 256 == -(-nq // 128) * 128)
     if big_shape and nq >= 2048 and 64 < k <= 200 and ld % 32 == 0 and n >= 1:
         return "gemm"                 # the 256 x 256 shape carries up to 200 keys per query, from 2048 queries
-    if nq >= 8 and 64 < k <= 1024 and ld % 32 == 0 and n >= 1024:
+    if nq >= 2 and 64 < k <= 1024 and ld % 32 == 0 and n >= 1024:
         return "gemm-segments"        # k beyond the selecting kernel: score matrix + selection per 32768-row segment, one merge
     return "scan"

@@ -143,12 +143,16 @@ def test_scores_path_matches_oracle(n, d, nq, k):
 @pytest.mark.parametrize("n,d,nq,k", [(100_000, 128, 40, 100), (65_537, 64, 300, 200), (40_000, 96, 9, 1024), (200_000, 32, 1100, 65),
                                        (32_769, 256, 8, 100), (1_500, 64, 20, 300), (98_304, 384, 600, 128),
                                        # the selecting kernel's 256 x 256 shape up to k = 200 (2048+ queries), the segment walk otherwise
-                                       (120_000, 64, 2048, 200), (60_000, 128, 2500, 100), (50_000, 96, 2100, 201), (90_000, 32, 1024, 150)])
+                                       (120_000, 64, 2048, 200), (60_000, 128, 2500, 100), (50_000, 96, 2100, 201), (90_000, 32, 1024, 150),
+                                       # groups of segments per launch: 32 + 2 segments under 3 queries (the last one of 17 rows),
+                                       # 20 + 2 under 50 queries (the 128 x 64 shape), 5 + 5 + 3 under 200, 2 and 5 queries
+                                       (33 * 32_768 + 17, 32, 3, 100), (700_000, 32, 50, 70), (400_000, 32, 200, 90),
+                                       (70_001, 64, 2, 65), (40_000, 96, 5, 1000)])
 def test_segments_path_matches_oracle(n, d, nq, k):
-    """k above 64 with 8 or more queries: the corpus is walked in segments of 32768 rows (score matrix on the matrix
-    cores, one selection workgroup per query and segment) and the per-segment lists are merged (path "gemm-segments").
-    Last segments of one row and of a few thousand, an exact tie across a segment boundary, masks, a threshold,
-    explicit ids, fewer hits than k."""
+    """k above 64 with 2 or more queries: the corpus is walked in segments of 32768 rows (score matrix on the matrix
+    cores, one selection workgroup per query and segment, several segments per launch under small batches) and the
+    per-segment lists are merged (path "gemm-segments").  Last segments of one row and of a few thousand, an exact tie
+    across a segment boundary, masks, a threshold, explicit ids, fewer hits than k."""
     from rag_amd import DeviceIndex
     rng = np.random.default_rng(n + nq + k)
     X = _unit(rng, n, d)
