@@ -259,8 +259,9 @@ int direct_select_launch(rag_index* h, long long nq, int k, float min_score, con
                          long long* I, hipStream_t s);
 int direct_select_rows(long long nq, int n, int k, float min_score, const uint8_t* mask, const long long* row_ids, long long id_base,
                        long long* rows_out, const float* scores, float* D, long long* I, hipStream_t s);
-int direct_select_segments(long long nq, long long n_row, int k, float min_score, const uint8_t* mask, const long long* row_ids,
-                           long long id_base, const float* scores, float* D, long long* I, long long out_stride, hipStream_t s);
+int direct_select_segments(long long nq, long long n_row, long long seg_rows, int k, float min_score, const uint8_t* mask,
+                           const long long* row_ids, long long id_base, const float* scores, float* D, long long* I, long long out_stride,
+                           hipStream_t s);
 
 bool direct_topk_supported(const rag_index* h, long long nq, int k) {
     static const int on = getenv("RAG_DIRECT_TOPK") ? atoi(getenv("RAG_DIRECT_TOPK")) : 1;          // measurement knob
@@ -320,13 +321,15 @@ int direct_select_rows(long long nq, int n, int k, float min_score, const uint8_
     return RAG_OK;
 }
 
-// a score row of n_row scores per query, taken as segments of 32768 rows (the last one shorter): one workgroup per
-// (query, segment); the list of segment g and query q starts at hit g * out_stride + q * k of D and I
-int direct_select_segments(long long nq, long long n_row, int k, float min_score, const uint8_t* mask, const long long* row_ids,
-                           long long id_base, const float* scores, float* D, long long* I, long long out_stride, hipStream_t s) {
+// a score row of n_row scores per query, taken as segments of seg_rows = 32768 rows (the last one shorter; the caller
+// states the segment length its output layout assumes): one workgroup per (query, segment); the list of segment g and
+// query q starts at hit g * out_stride + q * k of D and I
+int direct_select_segments(long long nq, long long n_row, long long seg_rows, int k, float min_score, const uint8_t* mask,
+                           const long long* row_ids, long long id_base, const float* scores, float* D, long long* I, long long out_stride,
+                           hipStream_t s) {
     const long long seg = (long long)SEL_REG_MAX * 1024;
     const long long segs = (n_row + seg - 1) / seg;
-    if (segs < 1 || nq * segs > 0x7fffffffLL) return fail(RAG_ERR_INVALID, "internal: segment selection grid");
+    if (seg_rows != seg || segs < 1 || nq * segs > 0x7fffffffLL) return fail(RAG_ERR_INVALID, "internal: segment selection grid");
     SelectArgs p = {};
     p.scores = scores;
     p.n = (int)seg;

@@ -1174,6 +1174,9 @@ bool gemm_segments_supported(const rag_index* h, long long nq, int k) {
 // small chunk of queries takes large groups, so that both launches have a few hundred workgroups, and the narrow
 // query shapes (256 x 32 up to 32 queries, 128 x 64 up to 64), which read the corpus once without multiplying padding
 // columns; from 1024 queries a segment alone fills the chip.
+bool narrow_scores_supported(const rag_index* h, long long nq);                                      // narrow_topk.hip
+int narrow_scores_launch(const rag_index* h, const float* X, long long rows, long long nq, const float* qbuf, float* scores,
+                         hipStream_t s);
 struct SegPlan {
     long long nseg, qc, group;
     size_t scores_bytes, d_bytes, i_bytes, keys_bytes;
@@ -1184,6 +1187,10 @@ static SegPlan seg_plan(const rag_index* h, long long nq, int k) {
     p.nseg = (h->n + SCORES_MAX_ROWS - 1) / SCORES_MAX_ROWS;
     p.qc = std::min<long long>(nq, seg_query_chunk(p.nseg, k));
     p.group = std::max<long long>(1, std::min<long long>(std::min<long long>(max_group, p.nseg), 1024 / p.qc));
+    // up to 32 queries on the register-streaming kernel: every launch stages the query block again, so the groups are as
+    // long as a score matrix of 512 MB allows (8 queries: the 10M rows of a corpus in one launch)
+    static const long long max_group_narrow = std::max(1, env_int_g("RAG_GEMM_SEGMENTS_GROUP_NARROW", 512));      // measurement knob
+    if (narrow_scores_supported(h, p.qc)) p.group = std::max<long long>(1, std::min<long long>(std::min<long long>(max_group_narrow, p.nseg), 4096 / p.qc));
     const long long group_rows = std::min<long long>(h->n, p.group * SCORES_MAX_ROWS);
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     p.scores_bytes = al((size_t)p.qc * group_rows * sizeof(float));
@@ -1197,8 +1204,9 @@ size_t gemm_segments_workspace(const rag_index* h, long long nq, int k) {
     return p.scores_bytes + p.d_bytes + p.i_bytes + p.keys_bytes;
 }
 
-int direct_select_segments(long long nq, long long n_row, int k, float min_score, const uint8_t* mask, const long long* row_ids,
-                           long long id_base, const float* scores, float* D, long long* I, long long out_stride, hipStream_t s);   // direct_topk.hip
+int direct_select_segments(long long nq, long long n_row, long long seg_rows, int k, float min_score, const uint8_t* mask,
+                           const long long* row_ids, long long id_base, const float* scores, float* D, long long* I, long long out_stride,
+                           hipStream_t s);   // direct_topk.hip
 
 int gemm_segments_search(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask, float* D,
                          long long* I, hipStream_t s) {
@@ -1218,6 +1226,15 @@ int gemm_segments_search(rag_index* h, long long nq, const float* qbuf, int k, f
         const int RT = QT == 32 ? 256 : QT == 64 ? 128 : QT;
         for (long long sg = 0; sg < p.nseg; sg += p.group) {
             const long long lo = sg * SCORES_MAX_ROWS, rows = std::min<long long>(p.group * SCORES_MAX_ROWS, h->n - lo);
+            if (narrow_scores_supported(h, qc)) {
+                // up to 32 queries: the register-streaming kernel reads the rows at the HBM rate (narrow_topk.hip)
+                if (int rc = narrow_scores_launch(h, h->X + (size_t)lo * h->ld, rows, qc, qbuf + (size_t)q0 * h->ld, scores, s)) return rc;
+                if (int rc2 = direct_select_segments(qc, rows, SCORES_MAX_ROWS, k, min_score, mask ? mask + lo : nullptr,
+                                                     h->ids_dev ? h->ids_dev + lo : nullptr, h->id_base + lo, scores,
+                                                     Dseg + (size_t)sg * qc * k, Iseg + (size_t)sg * qc * k, qc * k, s))
+                    return rc2;
+                continue;
+            }
             GemmArgs a = {};
             a.X = h->X + (size_t)lo * h->ld;
             a.Q = qbuf + (size_t)q0 * h->ld;
@@ -1240,8 +1257,8 @@ int gemm_segments_search(rag_index* h, long long nq, const float* qbuf, int k, f
             else if (QT == 64) rc = launch_gemm_store<128, 64, 4>(a, grid, h->device, s);
             else rc = launch_gemm_store<256, 32, 4>(a, grid, h->device, s);
             if (rc) return rc;
-            if (int rc2 = direct_select_segments(qc, rows, k, min_score, mask ? mask + lo : nullptr, h->ids_dev ? h->ids_dev + lo : nullptr,
-                                                 h->id_base + lo, scores, Dseg + (size_t)sg * qc * k, Iseg + (size_t)sg * qc * k, qc * k, s))
+            if (int rc2 = direct_select_segments(qc, rows, SCORES_MAX_ROWS, k, min_score, mask ? mask + lo : nullptr,
+                                                 h->ids_dev ? h->ids_dev + lo : nullptr, h->id_base + lo, scores, Dseg + (size_t)sg * qc * k, Iseg + (size_t)sg * qc * k, qc * k, s))
                 return rc2;
         }
         if (int rc = merge_lists_device((int)p.nseg, qc, k, Dseg, qc * k, Iseg, qc * k, D + (size_t)q0 * k, I + (size_t)q0 * k, keys, s)) return rc;

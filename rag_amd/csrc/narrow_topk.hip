@@ -81,6 +81,8 @@ struct NarrowArgs {
     int nq;
     int ld;                    // floats per row, multiple of 128
     int k;
+    float* scores;             // score-writing variant: [nq][n_row], row r of this launch's rows at column r
+    long long n_row;
 };
 
 // one K step (32 floats) of a 32-row tile as loaded: [row group][8-row half], 16 bytes per lane each
@@ -92,7 +94,9 @@ struct AChunk {
 // NSETS register sets of DEPTH chunks each rotate through the roles "being multiplied" and "in flight":
 // while one set feeds the MFMAs, the loads of the next NSETS - 1 groups are outstanding.  The number of
 // groups per row (ld / (16 * DEPTH)) is a multiple of NSETS, so every tile starts with the same rotation.
-template <int NJ, int DEPTH, int NSETS>
+// STORE: every score goes to a.scores and nothing is selected (no candidate buffers, thresholds or partial lists): what a
+// batch of up to 32 queries that asks for more keys than the selection carries runs per group of segments.
+template <int NJ, int DEPTH, int NSETS, bool STORE = false>
 __global__ __launch_bounds__(NR_WAVES * 64, NR_WAVES / 4) void narrow_topk_kernel(NarrowArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (a.run_if && *a.run_if == 0) return;
@@ -227,7 +231,8 @@ __global__ __launch_bounds__(NR_WAVES * 64, NR_WAVES / 4) void narrow_topk_kerne
 #pragma unroll
             for (int nj = 0; nj < NJ; ++nj) {
                 const int q = nj * 16 + r16;
-                tg_bits[nj] = __hip_atomic_load(&a.gthr[q < a.nq ? q : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if constexpr (STORE) tg_bits[nj] = 0u;
+                else tg_bits[nj] = __hip_atomic_load(&a.gthr[q < a.nq ? q : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             for (int gg = 0; gg < groups; gg += NSETS) {
 #pragma unroll
@@ -271,6 +276,27 @@ __global__ __launch_bounds__(NR_WAVES * 64, NR_WAVES / 4) void narrow_topk_kerne
 
             // ---- tile epilogue: lane (c = r16, kq) holds rows 4 kq .. 4 kq + 3 of each row group for query nj * 16 + c
             const long long row_base = a.row_begin + t * NR_TILE + kq * 4;
+            if constexpr (STORE) {
+                // four consecutive rows of one query per accumulator: a 16-byte store where the row count allows
+#pragma unroll
+                for (int nj = 0; nj < NJ; ++nj) {
+                    const int q = nj * 16 + r16;
+                    if (q >= a.nq) continue;
+#pragma unroll
+                    for (int rg = 0; rg < 2; ++rg) {
+                        const long long row = row_base + rg * 16;
+                        float* out = a.scores + (size_t)q * (size_t)a.n_row + row;
+                        if ((a.n_row & 3) == 0 && row + 3 < a.row_end) {
+                            *reinterpret_cast<f4*>(out) = (f4){acc[rg][nj][0], acc[rg][nj][1], acc[rg][nj][2], acc[rg][nj][3]};
+                        } else {
+#pragma unroll
+                            for (int reg = 0; reg < 4; ++reg)
+                                if (row + reg < a.row_end) out[reg] = acc[rg][nj][reg];
+                        }
+                    }
+                }
+                continue;
+            }
             // sort every buffer holding more than min_count keys, keep its k best, tighten the threshold
             auto compact = [&](int min_count) {
                 // the pushed keys are re-read through memory by other lanes of this wave: drain the stores first
@@ -355,6 +381,7 @@ __global__ __launch_bounds__(NR_WAVES * 64, NR_WAVES / 4) void narrow_topk_kerne
         }
     }
 
+    if constexpr (STORE) return;
     // ---- every query's k best keys of this wave ------------------------------------------------
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -443,6 +470,48 @@ static int launch_narrow_shape(const NarrowArgs& a, int nj, int grid, size_t lds
     const bool wide = (a.ld % 256) == 0;
     if (nj == 1) return wide ? launch_narrow<1, RAG_NARROW_DEPTH1, 4>(a, grid, lds, device, s) : launch_narrow<1, 1, 4>(a, grid, lds, device, s);
     return wide ? launch_narrow<2, RAG_NARROW_DEPTH2, 4>(a, grid, lds, device, s) : launch_narrow<2, 1, 4>(a, grid, lds, device, s);
+}
+
+// The score-writing variant for the segment walk: up to 32 queries against `rows` rows starting at X, every score to
+// scores[q * rows + r].  Same shapes as the selecting kernel (rows of a multiple of 128 floats, the query block in LDS).
+bool narrow_scores_supported(const rag_index* h, long long nq) {
+    static const int on = env_int_n("RAG_NARROW_SCORES", 1);          // measurement knob
+    if (!on || nq < 1 || nq > 32 || (h->ld % 128) != 0) return false;
+    return narrow_lds_bytes(h->ld, nq <= 16 ? 1 : 2) <= 160 * 1024;
+}
+
+template <int NJ, int DEPTH>
+static int launch_narrow_store(const NarrowArgs& a, int grid, size_t lds, int device, hipStream_t s) {
+    static bool attr_set[64] = {};
+    if (!attr_set[device & 63]) {
+        RAG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(narrow_topk_kernel<NJ, DEPTH, 4, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[device & 63] = true;
+    }
+    hipLaunchKernelGGL((narrow_topk_kernel<NJ, DEPTH, 4, true>), dim3(grid), dim3(NR_WAVES * 64), lds, s, a);
+    RAG_HIP_CHECK(hipGetLastError());
+    return RAG_OK;
+}
+
+int narrow_scores_launch(const rag_index* h, const float* X, long long rows, long long nq, const float* qbuf, float* scores,
+                         hipStream_t s) {
+    if (!narrow_scores_supported(h, nq) || rows < 1) return fail(RAG_ERR_INVALID, "internal: shape of the narrow score launch");
+    const int nj = nq <= 16 ? 1 : 2;
+    NarrowArgs a = {};
+    a.X = X;
+    a.Q = qbuf;
+    a.row_begin = 0;
+    a.row_end = rows;
+    a.nq = (int)nq;
+    a.ld = h->ld;
+    a.k = 1;
+    a.scores = scores;
+    a.n_row = rows;
+    const size_t lds = narrow_lds_bytes(h->ld, nj);
+    const int grid = narrow_grid(rows);
+    const bool wide = (a.ld % 256) == 0;
+    if (nj == 1) return wide ? launch_narrow_store<1, RAG_NARROW_DEPTH1>(a, grid, lds, h->device, s) : launch_narrow_store<1, 1>(a, grid, lds, h->device, s);
+    return wide ? launch_narrow_store<2, RAG_NARROW_DEPTH2>(a, grid, lds, h->device, s) : launch_narrow_store<2, 1>(a, grid, lds, h->device, s);
 }
 
 // qbuf: padded queries; the caller has sized h->ws with narrow_topk_workspace() behind them

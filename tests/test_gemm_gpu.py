@@ -147,7 +147,10 @@ def test_scores_path_matches_oracle(n, d, nq, k):
                                        # groups of segments per launch: 32 + 2 segments under 3 queries (the last one of 17 rows),
                                        # 20 + 2 under 50 queries (the 128 x 64 shape), 5 + 5 + 3 under 200, 2 and 5 queries
                                        (33 * 32_768 + 17, 32, 3, 100), (700_000, 32, 50, 70), (400_000, 32, 200, 90),
-                                       (70_001, 64, 2, 65), (40_000, 96, 5, 1000)])
+                                       (70_001, 64, 2, 65), (40_000, 96, 5, 1000),
+                                       # rows of a multiple of 128 floats under up to 32 queries: the register-streaming kernel writes the scores
+                                       (32 * 32_768 + 17, 128, 6, 70), (150_001, 768, 8, 200), (90_000, 384, 20, 100), (70_000, 256, 32, 65),
+                                       (1_030, 128, 2, 100), (140_000, 1024, 17, 80)])
 def test_segments_path_matches_oracle(n, d, nq, k):
     """k above 64 with 2 or more queries: the corpus is walked in segments of 32768 rows (score matrix on the matrix
     cores, one selection workgroup per query and segment, several segments per launch under small batches) and the
