@@ -122,7 +122,10 @@ int rag_index_load(const char* path, int device, rag_index_t** out);
  * vector_db/search_optimizer.py:146-274 search (nq = 1) and :276-323
  * batch_search (nq > 1), i.e. the client.search call at :213-222.
  *   q         nq x dim fp32
- *   k         hits per query (limit)
+ *   k         hits per query (limit), 1..1024.  Every k takes one pass over the corpus per
+ *             batch: up to 64 (200 from 2048 queries) the matrix-core kernel selects as it
+ *             scores; above that, from 2 queries, the scores of a group of 32768-row segments
+ *             are written out, selected per segment and the lists merged on the device
  *   min_score keep hits with score >= min_score (score_threshold); pass
  *             -FLT_MAX for none
  *   nprobe    IVF lists to scan (ignored by FLAT)
