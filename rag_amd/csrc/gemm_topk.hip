@@ -1110,7 +1110,8 @@ int gemm_scores_search(rag_index* h, long long nq, const float* qbuf, int k, flo
         p.nqb = (int)((nq + 127) / 128);
         p.nqb_pad = p.nqb > 8 ? ((p.nqb + 7) & ~7) : p.nqb;
         p.ntiles = (h->n + 127) / 128;
-        p.S = (int)std::max<long long>(1, std::min<long long>(p.ntiles, (512 + p.nqb_pad - 1) / p.nqb_pad));
+        // at most 512 workgroups (two per compute unit): one more would run alone after the others, for as long again
+        p.S = (int)std::max<long long>(1, std::min<long long>(p.ntiles, 512 / p.nqb_pad));
         p.gq = 0;
     }
     const size_t qbytes = ((size_t)nq * h->ld * sizeof(float) + 255) & ~(size_t)255;
@@ -1173,7 +1174,9 @@ bool gemm_segments_supported(const rag_index* h, long long nq, int k) {
 // ([queries][group * 32768] scores) and one selection launch runs a workgroup per (query, segment) of the group.  A
 // small chunk of queries takes large groups, so that both launches have a few hundred workgroups, and the narrow
 // query shapes (256 x 32 up to 32 queries, 128 x 64 up to 64), which read the corpus once without multiplying padding
-// columns; from 1024 queries a segment alone fills the chip.
+// columns.  Larger chunks take groups too (8192 (query, segment) pairs per launch, at most 32 segments): a workgroup of
+// the score launch then walks several tiles, which evens out batch sizes whose query-block count does not divide the
+// grid (768 queries: 3 blocks x 85 row ranges over the 128 tiles of one segment cost what 4 blocks cost).
 bool narrow_scores_supported(const rag_index* h, long long nq);                                      // narrow_topk.hip
 int narrow_scores_launch(const rag_index* h, const float* X, long long rows, long long nq, const float* qbuf, float* scores,
                          hipStream_t s);
@@ -1186,7 +1189,8 @@ static SegPlan seg_plan(const rag_index* h, long long nq, int k) {
     SegPlan p;
     p.nseg = (h->n + SCORES_MAX_ROWS - 1) / SCORES_MAX_ROWS;
     p.qc = std::min<long long>(nq, seg_query_chunk(p.nseg, k));
-    p.group = std::max<long long>(1, std::min<long long>(std::min<long long>(max_group, p.nseg), 1024 / p.qc));
+    static const long long group_pairs = std::max(1, env_int_g("RAG_GEMM_SEGMENTS_PAIRS", 8192));      // (query, segment) pairs per launch: a score matrix of at most 1 GB
+    p.group = std::max<long long>(1, std::min<long long>(std::min<long long>(max_group, p.nseg), group_pairs / p.qc));
     // up to 32 queries on the register-streaming kernel: every launch stages the query block again, so the groups are as
     // long as a score matrix of 512 MB allows (8 queries: the 10M rows of a corpus in one launch)
     static const long long max_group_narrow = std::max(1, env_int_g("RAG_GEMM_SEGMENTS_GROUP_NARROW", 512));      // measurement knob
@@ -1245,7 +1249,8 @@ int gemm_segments_search(rag_index* h, long long nq, const float* qbuf, int k, f
             a.k = k;
             a.nqb = (int)((qc + QT - 1) / QT);
             a.nqb_pad = a.nqb;
-            a.S = (int)std::max<long long>(1, std::min<long long>(a.ntiles, ((QT == 256 ? 256 : 512) + a.nqb_pad - 1) / a.nqb_pad));
+            // a grid of at most one (256 x 256) or two workgroups per compute unit: one more would run alone after the others
+            a.S = (int)std::max<long long>(1, std::min<long long>(a.ntiles, (QT == 256 ? 256 : 512) / a.nqb_pad));
             a.gq = 0;
             a.outc = k;
             a.trig = gemm_trig(RT, QT, GEMM_MAX_K);

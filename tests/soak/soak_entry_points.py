@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity run of the entry points behind the callers of the search: segment search, fused
 fan-out, search -> fusion -> MMR pipeline (flat and IVF), keyword ranking, the several-GPU index
-replayed on one GPU.  Each case draws its shape from SEED (SEED=first:last) and goes through the
+replayed on one GPU.  Each case draws its shape from its seed (SEEDS=first:last) and goes through the
 checker of the collected test of the same entry point; prints one line per seed and section."""
 import os
 import random
