@@ -863,26 +863,44 @@ static GemmPlan gemm_plan(const rag_index* h, long long nq, int k) {
     p.NW = p.QT == 256 ? 8 : 4;
     const int target_wgs = target_wgs_env > 0 ? target_wgs_env : (p.NW == 8 ? 256 : 512);
     p.nqb = (int)((nq + p.QT - 1) / p.QT);
-    p.nqb_pad = p.nqb > 8 ? ((p.nqb + 7) & ~7) : p.nqb;
-    long long s = target_wgs / p.nqb_pad;
-    if (s < 1) s = 1;
     // a row range should hold at least 8 tiles, or splitting costs more than it spreads -- unless the grid would
     // then leave compute units without a workgroup (a short corpus under a large batch: the 16384 centroids of an
     // IVF index under 4096 queries are 64 tiles for 16 query blocks), where ranges go down to one tile
     static const int min_tiles_short = std::max(1, env_int_g("RAG_GEMM_MIN_TILES_SHORT", 1));      // measurement knob
     p.ntiles = (h->n + p.RT - 1) / p.RT;
     long long max_s = (p.ntiles + 7) / 8;
-    if (max_s * p.nqb_pad < target_wgs) max_s = std::max(max_s, (p.ntiles + min_tiles_short - 1) / min_tiles_short);
-    if (s > max_s) s = max_s < 1 ? 1 : max_s;
-    p.S = (int)s;
-    // placement over the XCDs: the widest split of the query blocks that the counts allow
+    if (max_s * p.nqb < target_wgs) max_s = std::max(max_s, (p.ntiles + min_tiles_short - 1) / min_tiles_short);
+    if (max_s < 1) max_s = 1;
+    // Query blocks x row ranges = at most target_wgs workgroups (one round on the chip).  Placement over the XCDs (gq > 0:
+    // XCD x owns query-block group x % gq and row-range group x / gq) needs the block count padded to a multiple of gq
+    // and the range count a multiple of 8 / gq; padding blocks exit at once, so a padded grid leaves compute units idle
+    // (9 blocks padded to 16 x 16 ranges: 144 of 256 workgroups, and 2304 queries took as long as 4096).  Of the
+    // placements gq = 8, 4, 2, 1 and the plain one (gq = 0, no padding) the one with the most working workgroups is
+    // taken, the widest split on a tie.
     static const int gq_env = env_int_g("RAG_GEMM_GQ", -1);
+    long long best_active = -1;
+    p.nqb_pad = p.nqb;
+    p.S = 1;
     p.gq = 0;
-    for (int gq = (gq_env >= 0 ? gq_env : 8); gq >= 1; gq >>= 1) {
-        if (p.nqb_pad % gq == 0 && p.S % (8 / gq) == 0 && ((long long)p.nqb_pad * p.S) % 8 == 0) { p.gq = gq; break; }
-        if (gq_env >= 0) break;
+    for (int gq = 8; gq >= 0; gq = gq > 1 ? gq >> 1 : gq - 1) {
+        if (gq_env >= 0 && gq != gq_env) continue;
+        const long long pad = gq > 0 ? (p.nqb + gq - 1) / gq * gq : p.nqb;
+        long long s = std::min<long long>(target_wgs / pad, max_s);
+        if (gq > 0) s -= s % (8 / gq);
+        if (s < 1) continue;
+        const long long active = (long long)p.nqb * s;
+        if (active > best_active) {
+            best_active = active;
+            p.nqb_pad = (int)pad;
+            p.S = (int)s;
+            p.gq = gq;
+        }
     }
-    if (gq_env == 0) p.gq = 0;
+    if (best_active < 0) {           // more query blocks than workgroups in a round (or a forced placement that does not fit)
+        p.nqb_pad = p.nqb;
+        p.S = 1;
+        p.gq = 0;
+    }
     p.cand_bytes = (size_t)p.nqb_pad * p.S * p.QT * gemm_capq(p.RT, p.QT) * sizeof(u64);
     p.part_bytes = ((size_t)nq * p.S * k * sizeof(u64) + 255) & ~(size_t)255;
     p.gthr_bytes = ((size_t)nq * sizeof(unsigned int) + 255) & ~(size_t)255;
@@ -1108,7 +1126,7 @@ int gemm_scores_search(rag_index* h, long long nq, const float* qbuf, int k, flo
     if (p.QT != 256) {                       // 128 .. 1023 queries: the 128 x 128 shape
         p.QT = 128; p.RT = 128; p.NW = 4;
         p.nqb = (int)((nq + 127) / 128);
-        p.nqb_pad = p.nqb > 8 ? ((p.nqb + 7) & ~7) : p.nqb;
+        p.nqb_pad = p.nqb;                    // plain placement (gq = 0): nothing to pad for
         p.ntiles = (h->n + 127) / 128;
         // at most 512 workgroups (two per compute unit): one more would run alone after the others, for as long again
         p.S = (int)std::max<long long>(1, std::min<long long>(p.ntiles, 512 / p.nqb_pad));

@@ -15,7 +15,6 @@ rows = int(os.environ.get("ROWS", 10_000_000))
 dim = int(os.environ.get("DIM", 768))
 dev = torch.device("cuda", 0)
 X = make_corpus(torch, 0, rows, dim, dev)
-Q = make_queries(torch, 4096, dim, dev)
 idx = DeviceIndex(dim, metric="ip")
 idx.adopt(X)
 cases = [(8, 100), (32, 100), (64, 100), (64, 64), (128, 200), (256, 200), (512, 200), (1024, 200), (4096, 200), (256, 1024)]
@@ -23,6 +22,7 @@ if os.environ.get("CASES"):                          # "nq:k,nq:k"
     cases = [tuple(int(v) for v in c.split(":")) for c in os.environ["CASES"].split(",")]
 elif os.environ.get("RAG_GEMM_SEGMENTS_MIN_NQ") == "0":
     cases = [(8, 100), (64, 100), (64, 64)]          # the per-query scans of larger batches take minutes
+Q = make_queries(torch, max(4096, max(nq for nq, _ in cases)), dim, dev)
 for nq, k in cases:
     idx.search(Q[:nq], k)
     torch.cuda.synchronize()
