@@ -234,8 +234,9 @@ def _check_batch(idx, X, Q, topn, bm_rows, bm_scores, to_rows, to_id, *, max_res
 def test_batched_pipeline_equals_the_oracle_per_query():
     """rag_index_hybrid_mmr_batch_device: one search for every query's top-N, then fusion and MMR per query.  Each query's
     result is checked exactly against the oracle's fusion + MMR fed with the scores of that search (the same search as a plain
-    call: 12 queries at k = 200 take the segment walk, 3 queries the scan), on a flat index with explicit ids and a mask, one
-    with an id base, and an IVF index; keyword lists are padded with -1."""
+    call: at k = 200 both 12 and 3 queries take the segment walk), on a flat index with explicit ids and a mask, one
+    with an id base, and an IVF index; keyword lists are padded with -1.  600 queries span two chunks of the tail launches
+    (512 queries per launch)."""
     from rag_amd import DeviceIndex
     rng = np.random.default_rng(21)
     n, d = 70_000, 128
@@ -257,7 +258,8 @@ def test_batched_pipeline_equals_the_oracle_per_query():
     by_base = (lambda I: np.where(I >= 0, I - 1000, -1), lambda r: r + 1000)
     plain = (lambda I: I, lambda r: r)
     for idx, nq, topn, nb, kw, (to_rows, to_id) in ((flat_ids, 12, 200, 60, {"row_mask": mask}, by_ids), (flat_base, 3, 200, 100, {}, by_base),
-                                                    (flat_base, 9, 64, 0, {"min_score": 0.3}, by_base), (iv, 10, 150, 40, {"nprobe": 8}, plain)):
+                                                    (flat_base, 9, 64, 0, {"min_score": 0.3}, by_base), (iv, 10, 150, 40, {"nprobe": 8}, plain),
+                                                    (flat_base, 600, 70, 20, {}, by_base)):
         Q = np.stack([cent[i % cent.shape[0]] / np.linalg.norm(cent[i % cent.shape[0]]) for i in range(nq)]).astype(np.float32)
         Q += 0.02 * rng.standard_normal(Q.shape).astype(np.float32)
         bm_rows = rng.integers(0, n, (nq, nb)).astype(np.int64)
