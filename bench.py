@@ -119,6 +119,59 @@ def make_queries(torch, nq, dim, device):
     return q
 
 
+def same_topk(torch, Da, Ia, Db, Ib, rtol=1e-5, atol=1e-6):
+    """Two answers for the same queries from different kernels: score lists agree position by position
+    within rtol*|s| + atol, and an id held by one side only scores within that bound of the other side's
+    last kept score (a tie at the cut).  The summation orders differ, so exact ties may swap places."""
+    Da, Db = Da.double(), Db.double()
+    tol = rtol * Db.abs() + atol
+    if not bool(((Da - Db).abs() <= tol).all()):
+        return False
+    for q in range(Ia.shape[0]):
+        a, b = Ia[q].tolist(), Ib[q].tolist()
+        if len(set(a)) != len(a):
+            return False
+        sa, sb = dict(zip(a, Da[q].tolist())), dict(zip(b, Db[q].tolist()))
+        cut = float(tol[q, -1])
+        for i in set(a) - set(b):
+            if abs(sa[i] - float(Db[q, -1])) > cut:
+                return False
+        for i in set(b) - set(a):
+            if abs(sb[i] - float(Da[q, -1])) > cut:
+                return False
+    return True
+
+
+def rescored_ok(torch, X, Q, D, I, lo, hi, rtol=1e-5, atol=1e-6):
+    """Scores against an fp64 re-score of the returned rows this rank holds (ids in [lo, hi)); lists
+    descending, ids in the corpus."""
+    if not bool((D[:, 1:] <= D[:, :-1]).all()):
+        return False
+    own = (I >= lo) & (I < hi)
+    if not bool(((I >= 0) | (D < -1e38)).all()):
+        return False
+    ok = True
+    step = 512
+    for a in range(0, I.shape[0], step):
+        Ic = (I[a:a + step] - lo).clamp(0, hi - lo - 1)
+        rows = X[Ic.reshape(-1)].double().reshape(Ic.shape + (X.shape[1],))
+        ref = torch.einsum("qkd,qd->qk", rows, Q[a:a + step].double())
+        err = (D[a:a + step].double() - ref).abs()
+        ok = ok and bool(((err <= rtol * ref.abs() + atol) | ~own[a:a + step]).all())
+    return ok
+
+
+def sample_queries(B, block=256, extra=8):
+    """First and last query of every 256-query block plus a few in between (at most ~40)."""
+    qs = set()
+    for b in range(0, B, block):
+        qs.add(b)
+        qs.add(min(B, b + block) - 1)
+    step = max(1, B // extra)
+    qs.update(range(step // 2, B, step))
+    return sorted(qs)
+
+
 def timed_steps(torch, dist, world, step, nwarm, nsteps, device):
     """nwarm untimed steps, then exactly nsteps timed ones between barrier + device
     synchronisation on both sides; the time returned is the maximum over the ranks."""
@@ -467,8 +520,19 @@ def leg_small_corpus(torch, args, device, rows=100_000, dim=384, k=10):
     dtb = time.perf_counter() - t0
     kb, lb = idx.profile_read(reset=True)
     tf = 2.0 * 4096 * rows * dim / (kb / max(lb, 1) * 1e-3) / 1e12 if lb else 0.0
+    idx.profile(False)
+    Db, Ib = idx.search(Q, k)
+    path_b = idx.last_path
+    okb = rescored_ok(torch, X, Q, Db, Ib, 0, rows)
+    ok1 = True
+    for qi in sample_queries(4096):
+        D1, I1 = idx.search(Q[qi:qi + 1], k)
+        ok1 = ok1 and rescored_ok(torch, X, Q[qi:qi + 1], D1, I1, 0, rows)
+        okb = okb and same_topk(torch, Db[qi:qi + 1], Ib[qi:qi + 1], D1, I1)
+    path_1 = idx.last_path
     idx.close()
     return {"value": nsteps / dt, "unit": "queries/sec", "batch": 1, "us_per_query": dt / nsteps * 1e6,
+            "verified": {"batch_1": bool(ok1), "batch_4096": bool(okb)}, "paths": {"batch_1": path_1, "batch_4096": path_b},
             "scan_kernel_us": scan_us, "workload": f"exact flat top-{k}, {rows}x{dim} fp32, batch 1",
             "roofline": {"bound": "hbm", "kernel": "flat_scan_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gbs / HBM_PEAK_GBS, "traffic": None, "kernel_ms": scan_us * 1e-3, "launches": launches,
@@ -562,6 +626,22 @@ def leg_ivf_share(torch, args, device, rows=12_500_000, dim=1024, nlist=16384, n
                                "note": "every probed list read once (lists probed by more than 32 queries are read again)",
                                "mfma_TFLOPs": tf, "mfma_frac_of_fp32_peak": tf / FP32_MFMA_PEAK_TFLOPS}
         out["batch_%d" % nq] = leg
+    # answers of the two timed paths: the batch's lists against per-query searches of sampled queries (another scan
+    # kernel over the same probed lists), every sampled score re-computed in fp64 from the stored rows, and the
+    # query's own base row (a row of the corpus 0.3 sigma away) found
+    ivf.profile(False)
+    Db, Ib = ivf.search(Q, k, nprobe=nprobe)
+    ok_b, ok_1 = bool((Db[:, 1:] <= Db[:, :-1]).all()), True
+    import numpy as np
+    for qi in sample_queries(Q.shape[0]):
+        D1, I1 = ivf.search(Q[qi:qi + 1], k, nprobe=nprobe)
+        ok_b = ok_b and same_topk(torch, Db[qi:qi + 1], Ib[qi:qi + 1], D1, I1)
+        ids = I1[0].cpu().numpy()
+        rows_h = ivf.reconstruct(ids[ids >= 0]).astype(np.float64)
+        ref = rows_h @ Q[qi].cpu().numpy().astype(np.float64)
+        got = D1[0].cpu().numpy().astype(np.float64)[ids >= 0]
+        ok_1 = ok_1 and bool(np.all(np.abs(got - ref) <= 1e-5 * np.abs(ref) + 1e-6)) and bool(np.all(np.diff(got) <= 0))
+    out["verified"] = {"batch_1": ok_1, "batch_4096": ok_b}
     ivf.close()
     return out
 
@@ -638,6 +718,42 @@ def main(argv=None):
              "kernel_ms": k_avg_ms, "launches": launches,
              "algorithmic_bytes_per_launch": (hi - lo) * bytes_per_row}
 
+    # ---------------- what the timed legs answered, checked outside every timed region ----------------
+    # single-query fp32 scans of a sample of the queries are the reference the batch legs are held to; the batch-1
+    # leg itself is held to a 64-query batch (another kernel); every score is re-computed in fp64 from the rows
+    verified = {}
+    index.profile(False)
+    ref_q = sample_queries(args.big_batch)
+    ref_scan = {qi: search(Q[qi:qi + 1], k) for qi in ref_q}
+    ref_path = index.last_path
+    nb64 = min(64, args.big_batch)
+    D64, I64 = search(Q[:nb64], k)
+    other_path = index.last_path
+    ok1 = True
+    for qi in [q for q in ref_q if q < nb64]:
+        Dq, Iq = ref_scan[qi]
+        ok1 = ok1 and same_topk(torch, Dq, Iq, D64[qi:qi + 1], I64[qi:qi + 1])
+    for qi in ref_q[:8]:
+        Dq, Iq = ref_scan[qi]
+        ok1 = ok1 and rescored_ok(torch, X, Q[qi:qi + 1], Dq, Iq, lo, hi)
+    verified["batch_1"] = bool(ok1)
+    verify_paths = {"single_query_reference": ref_path, "batch_1_checked_against_batch_%d" % nb64: other_path}
+    del D64, I64
+    index.profile(True)
+
+    def verify_batch(B):
+        """The batch a leg timed, answered once more (profiling off) and checked: every list re-scored in fp64,
+        the sampled queries against their single-query scans."""
+        index.profile(False)
+        Db, Ib = search(Q[:B], k)
+        ok = rescored_ok(torch, X, Q[:B], Db, Ib, lo, hi)
+        for qi in [q for q in ref_q if q < B]:
+            Dq, Iq = ref_scan[qi]
+            ok = ok and same_topk(torch, Db[qi:qi + 1], Ib[qi:qi + 1], Dq, Iq)
+        index.profile(True)
+        index.profile_read(reset=True)
+        return bool(ok)
+
     # ---------------- batch 4096 (and a serving-sized batch) ----------------
     def batch_leg(B, nsteps, peak_tflops=FP32_MFMA_PEAK_TFLOPS):
         def stepb(i):
@@ -677,11 +793,14 @@ def main(argv=None):
     big = mid = None
     if not args.no_big:
         big = batch_leg(args.big_batch, args.big_steps or min(args.steps, 5))
+        verified["batch_%d" % args.big_batch] = verify_batch(args.big_batch)
     mid16 = None
     if args.mid_batch > 0:
         mid = batch_leg(min(args.mid_batch, args.big_batch), min(args.steps, 20))
+        verified["batch_%d" % mid["batch"]] = verify_batch(mid["batch"])
         if args.mid_batch > 16:
             mid16 = batch_leg(16, min(args.steps, 20))
+            verified["batch_16"] = verify_batch(16)
     # opt-in mode, reported beside the fp32 numbers and never as `value`: bf16 first pass on the
     # matrix cores + fp32 re-scoring of the rows within the error margin (same answers)
     pre = pre1 = pre_mid = None
@@ -690,9 +809,11 @@ def main(argv=None):
         pre = batch_leg(args.big_batch, args.big_steps or min(args.steps, 5), BF16_MFMA_PEAK_TFLOPS)
         pre["roofline"]["traffic"] = None
         pre["dtype"] = "bf16 first pass (fp32 accumulate) + f32 re-score of the kept rows"
+        verified["batch_%d_bf16_first_pass" % args.big_batch] = verify_batch(args.big_batch)
         if mid is not None:      # the serving-sized batch: one pass over the bf16 copy in the narrow shape
             pre_mid = batch_leg(mid["batch"], min(args.steps, 20), BF16_MFMA_PEAK_TFLOPS)
             pre_mid["dtype"] = pre["dtype"]
+            verified["batch_%d_bf16_first_pass" % mid["batch"]] = verify_batch(mid["batch"])
             r = pre_mid["roofline"]                 # one pass over the bf16 rows (half the bytes): HBM-bound
             gb = r["corpus_GBps"] / 2
             pre_mid["roofline"] = {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -714,6 +835,11 @@ def main(argv=None):
                 "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                              "traffic": None, "kernel_ms": kp / max(lp, 1), "launches": lp,
                              "algorithmic_bytes_per_launch": (hi - lo) * args.dim * 2}}
+        okp = True
+        for qi in ref_q[:8]:
+            Dp, Ip = search(Q[qi:qi + 1], k)
+            okp = okp and same_topk(torch, Dp, Ip, *ref_scan[qi]) and rescored_ok(torch, X, Q[qi:qi + 1], Dp, Ip, lo, hi)
+        verified["batch_1_bf16_first_pass"] = bool(okp)
         index.set_prefilter(False)
     index.profile(False)
 
@@ -726,6 +852,13 @@ def main(argv=None):
         nrows = min(args.cpu_rows, hi - lo)
         cpu = cpu_baseline(torch, X[:nrows], Q, k, args.rows, args.big_batch)
 
+    if world > 1:
+        # a rank re-scores the rows it holds: the run passes only if every rank's checks did
+        on_host = dist.get_backend() == "gloo"
+        flag = torch.tensor([1 if all(verified.values()) else 0], dtype=torch.int32, device="cpu" if on_host else device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if not int(flag.item()):
+            verified["every_rank"] = False
     if rank == 0:
         out = {
             "metric": f"queries/sec, top-{k} exact IP, {args.rows}x{args.dim} fp32, batch 1",
@@ -740,6 +873,10 @@ def main(argv=None):
                        "exchange": "none" if world == 1 else "1 all-gather of (score,id) + device merge",
                        "dist_backend": None if world == 1 else args.dist_backend},
             "roofline": roof1,
+            "verified": verified, "verified_how": dict(verify_paths, rule=(
+                "outside the timed regions: each leg's batch answered once more, every list re-scored in fp64 from the rows "
+                "(1e-5 relative + 1e-6), ids of sampled queries (first and last of every 256-query block and 8 more) equal to "
+                "their single-query fp32 scans except at ties within that bound")),
         }
         if big is not None:
             out["batch_%d" % args.big_batch] = big
@@ -764,10 +901,16 @@ def main(argv=None):
             side["config1_100k_384"] = leg_small_corpus(torch, args, device)
             side["ivf_per_gpu_share"] = leg_ivf_share(torch, args, device)
         out.update(side)
+        for name, leg in side.items():
+            if isinstance(leg, dict) and "verified" in leg:
+                verified[name] = leg["verified"] if isinstance(leg["verified"], bool) else all(leg["verified"].values())
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and not all(verified.values()):
+        print(f"error: a timed leg returned answers that fail verification: {verified}", file=sys.stderr)
+        sys.exit(5)
 
 
 if __name__ == "__main__":

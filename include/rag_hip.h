@@ -167,15 +167,21 @@ int rag_index_search_segments_fused(rag_index_t* h, int64_t nq, const float* q, 
                                     int k, float min_score, const uint8_t* row_mask, int limit,
                                     int64_t* out_rows, double* out_scores, int32_t* out_strategy,
                                     int32_t* n_out);
-/* which kernel path the last search on this index used ("scan", "gemm", "ivf", "ivf-listmajor",
- * "segments", "segments-fused", "direct", "scan-bf16", "gemm-bf16") */
+/* which kernel path the last search on this index used: "none", "empty", "scan" (1-4 queries, HBM scan), "direct" (1-4
+ * queries over <= 32768 rows), "narrow" (5-32 queries, one HBM-rate pass on the matrix cores), "gemm" (the selecting
+ * matrix-core kernel), "gemm-scores" (large batch over a short corpus: score matrix + selection), "gemm-segments" (batches
+ * with k above 64: the same per 32768-row segment), "scan-bf16" / "gemm-bf16" (opt-in bf16 first pass + fp32 re-score),
+ * "ivf" (per-query list scan), "ivf-listmajor" (batched list scan on the matrix cores), "segments", "segments-fused" */
 const char* rag_index_last_path(const rag_index_t* h);
 
 /* multi-GPU step after the all-gather of per-shard results: merge `nlists`
  * result sets, list g at D_dev + g*d_list_stride / I_dev + g*i_list_stride
  * (strides in elements; 0 = dense nq*k), each [nq][k], into the k best per
  * query (same order rule; ids are final ids here; ties between lists go to the
- * lower list).  Device buffers, enqueued on `stream`. */
+ * lower list).  Device buffers, enqueued on `stream`.  The candidate keys go through a
+ * grow-only device block that belongs to the calling host thread: merges that one host thread
+ * issues on DIFFERENT streams share it and must not overlap (keep a thread's merges on one
+ * stream, or synchronise between them). */
 int rag_merge_topk_device(int nlists, int64_t nq, int k, const float* D_dev, int64_t d_list_stride,
                           const int64_t* I_dev, int64_t i_list_stride, float* D_out_dev,
                           int64_t* I_out_dev, int device, void* stream);
@@ -186,8 +192,9 @@ int rag_merge_topk_device(int nlists, int64_t nq, int k, const float* D_dev, int
  * per GPU held until the process ends (RAG_MERGE_STATIC_MAX_KEYS * 8 bytes = 8 MiB).  Limit:
  * nq * nlists * k <= RAG_MERGE_STATIC_MAX_KEYS, beyond which it returns RAG_ERR_INVALID.  Every
  * call on a GPU shares that GPU's array: calls that overlap on one GPU (different streams or
- * threads) race; calls on one stream are ordered.  Same arguments and results as
- * rag_merge_topk_device. */
+ * threads) race; calls on one stream are ordered.  The first call on a device looks up the
+ * array's address (and k > 64 may set a kernel attribute once): make that call outside a graph
+ * capture.  Same arguments and results as rag_merge_topk_device. */
 #define RAG_MERGE_STATIC_MAX_KEYS (1 << 20)
 int rag_merge_topk_device_static(int nlists, int64_t nq, int k, const float* D_dev, int64_t d_list_stride,
                                  const int64_t* I_dev, int64_t i_list_stride, float* D_out_dev,
@@ -254,9 +261,14 @@ int rag_mmr_select_rows(rag_index_t* h, int64_t n, const int64_t* rows, const do
  * the row-sharded index inside the process: rows of every add are dealt over the devices in
  * contiguous parts, a search runs on all devices at once (one host thread per device) and the
  * per-device answers are merged under the library's order rule (score descending, ties to the
- * lower id).  Same arguments and results as the rag_index_* call of the same name; ids == NULL
- * numbers the rows 0, 1, 2, ... in the order they were added, as a single index would.
- * device_ids may name a device more than once (two shards on one GPU). */
+ * lower id).  The merge runs on the first device: every device copies its k-per-query lists
+ * there peer to peer and one kernel merges them, so only the merged nq x k answer crosses to the
+ * host; where a device cannot reach the first one peer to peer the lists are merged on the host
+ * (rag_multi_last_merge says which: "device" / "host").  Same arguments and results as the
+ * rag_index_* call of the same name; ids == NULL numbers the rows 0, 1, 2, ... in the order they
+ * were added, as a single index would.  An add is all or nothing: when a device fails, the parts
+ * the other devices took are given back.  device_ids may name a device more than once (two
+ * shards on one GPU). */
 typedef struct rag_multi rag_multi_t;
 int rag_multi_create(int dim, int metric, int kind, int n_devices, const int* device_ids, rag_multi_t** out);
 int rag_multi_free(rag_multi_t* h);
@@ -272,6 +284,8 @@ int rag_multi_set_active(rag_multi_t* h, int64_t n, const int64_t* rows, int act
 int rag_multi_reconstruct(rag_multi_t* h, int64_t n, const int64_t* rows, float* out);
 int rag_multi_search(rag_multi_t* h, int64_t nq, const float* q, int k, float min_score, int nprobe,
                      const uint8_t* row_mask, float* D, int64_t* I);
+/* where the last rag_multi_search merged the devices' lists: "device", "host" or "none" */
+const char* rag_multi_last_merge(const rag_multi_t* h);
 
 /* ---- keyword side: BM25 over a token-id corpus in device memory -----------------------
  * vector_db/search_manager.py:142-180 (CorpusStatsManager.calculate_bm25_score), :182-263

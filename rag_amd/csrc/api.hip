@@ -457,7 +457,14 @@ static int add_common(rag_index_t* h, int64_t n, const float* x, bool x_on_devic
     if (int rc = append_ids(h, n, ids)) return rc;
     const long long first = h->n;
     h->n += n;
-    if (h->kind == RAG_KIND_IVF) return ivf_assign_new_rows(h, first, n);
+    if (h->kind == RAG_KIND_IVF) {
+        if (int rc = ivf_assign_new_rows(h, first, n)) {
+            // rows without a list cannot stay: the add did not happen
+            h->n = first;
+            if (h->ivf.assign.size() > (size_t)first) h->ivf.assign.resize((size_t)first);
+            return rc;
+        }
+    }
     return RAG_OK;
 }
 
@@ -672,6 +679,27 @@ static int search_device_ordered(rag_index* h, int64_t nq, const float* q_dev, i
 }  // extern "C"
 
 namespace rag {
+// Forget the rows at and behind position n -- the way a caller that spreads one add over several indexes takes back
+// the parts that went through when another part failed.  Only rows that no search has seen: an IVF index must not
+// have packed them into its lists yet (they still wait at the tail in arrival order).
+int index_truncate(rag_index* h, long long n) {
+    RAG_LOCK_INDEX(h);
+    if (n < 0 || n > h->n) return fail(RAG_ERR_INVALID, "truncate: row count out of range");
+    if (n == h->n) return RAG_OK;
+    if (h->adopted) return fail(RAG_ERR_INVALID, "truncate: the rows are in an adopted buffer");
+    if (h->kind == RAG_KIND_IVF) {
+        if (h->ivf.n_packed > n) return fail(RAG_ERR_INVALID, "truncate: rows are already packed into their lists");
+        if (h->ivf.assign.size() > (size_t)n) h->ivf.assign.resize((size_t)n);
+    }
+    DeviceGuard g(h->device);
+    if (int rc = ws_acquire(h, h->stream)) return rc;
+    RAG_HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (h->active) RAG_HIP_CHECK(hipMemset(h->active + n, 1, (size_t)(h->n - n)));       // a later add starts with active rows
+    if (h->xb_rows > n) h->xb_rows = n;
+    h->n = n;
+    return RAG_OK;
+}
+
 // a search enqueued for another entry point of the library (index locked, device current, workspaces acquired)
 int search_device_enqueue(rag_index* h, int64_t nq, const float* q_dev, int k, float min_score, int nprobe,
                           const uint8_t* row_mask_dev, float* D_dev, int64_t* I_dev, hipStream_t s) {

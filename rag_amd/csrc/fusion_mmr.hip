@@ -1306,8 +1306,7 @@ int rag_index_hybrid_mmr_batch_device(rag_index_t* h, int64_t nq, const float* q
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc = ws_acquire(h, s)) return rc;
     // fusion and MMR run for a chunk of queries at a time (one launch per stage, blockIdx.y = query), every query of a chunk
-    // with its own set of the plan's buffers; the per-query arguments are built here and copied to the device up front
-    // (they hold addresses only, nothing the search produces)
+    // with its own set of the plan's buffers; the per-query arguments hold addresses only, nothing the search produces
     const size_t tail_bytes = al256(pl.total);
     const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(nq, 512), (int64_t)(((size_t)2 << 30) / tail_bytes)));
     const size_t ab = al256((size_t)nq * sizeof(TailArgs));
@@ -1318,6 +1317,18 @@ int rag_index_hybrid_mmr_batch_device(rag_index_t* h, int64_t nq, const float* q
     float* Dall = reinterpret_cast<float*>(w + (size_t)chunk * tail_bytes + ab);
     long long* Rall = reinterpret_cast<long long*>(w + (size_t)chunk * tail_bytes + ab + db);
     const int M = pl.M;
+    // 1. the semantic top-N of all queries as ONE search.  It leaves row positions (the id table and base are set aside for
+    //    it: the index is locked and they are read when a launch is built); ids are named when the hits are final
+    long long* const ids = h->ids_dev;
+    const long long base = h->id_base;
+    h->ids_dev = nullptr;
+    h->id_base = 0;
+    const int rc = search_device_enqueue(h, nq, q_dev, topn, min_score, nprobe, row_mask_dev, Dall, reinterpret_cast<int64_t*>(Rall), s);
+    h->ids_dev = ids;
+    h->id_base = base;
+    if (rc) return rc;
+    // 2. the per-query kernel arguments, built only now: an IVF search may have re-packed the rows (a new X, a new
+    //    insertion -> storage map), and the arguments hold those addresses
     {
         // pinned staging that belongs to the index; the event says when the last copy out of it has been made
         if (h->tail_args_cap < (size_t)nq * sizeof(TailArgs)) {
@@ -1344,17 +1355,7 @@ int rag_index_hybrid_mmr_batch_device(rag_index_t* h, int64_t nq, const float* q
         RAG_HIP_CHECK(hipMemcpyAsync(args_dev, host, (size_t)nq * sizeof(TailArgs), hipMemcpyHostToDevice, s));
         RAG_HIP_CHECK(hipEventRecord(h->tail_args_event, s));
     }
-    // 1. the semantic top-N of all queries as ONE search.  It leaves row positions (the id table and base are set aside for
-    //    it: the index is locked and they are read when a launch is built); ids are named when the hits are final
-    long long* const ids = h->ids_dev;
-    const long long base = h->id_base;
-    h->ids_dev = nullptr;
-    h->id_base = 0;
-    const int rc = search_device_enqueue(h, nq, q_dev, topn, min_score, nprobe, row_mask_dev, Dall, reinterpret_cast<int64_t*>(Rall), s);
-    h->ids_dev = ids;
-    h->id_base = base;
-    if (rc) return rc;
-    // 2. fusion and MMR behind it on the same stream, a chunk of queries per launch
+    // 3. fusion and MMR behind it on the same stream, a chunk of queries per launch
     RAG_HIP_CHECK(hipMemsetAsync(ids_dev, 0xFF, (size_t)nq * M * sizeof(int64_t), s));        // slots past a query's count: -1
     RAG_HIP_CHECK(hipMemsetAsync(n_out_dev, 0, (size_t)nq * sizeof(int32_t), s));
     for (int64_t q0 = 0; q0 < nq; q0 += chunk)

@@ -3,8 +3,13 @@
 // answers a search with a blocking call inside a single worker process
 // (vector_db/search_optimizer.py:213-222).  Host code only: every shard is an ordinary
 // rag_index_t on its device, driven by one persistent host thread per shard so that the
-// devices scan at the same time; the per-device answers (k per query) are merged on the host.
+// devices scan at the same time.  The per-device answers (k per query) stay in HBM: every
+// shard copies its lists peer to peer into a buffer on the first device, where one kernel
+// merges them (score order, ties to the lower id) and only the merged nq x k answer comes
+// back to the host.  Where a device cannot reach the first one peer to peer, the lists go
+// through the host and are merged there.
 #include <float.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -92,16 +97,32 @@ struct Piece {
 
 }  // namespace
 
+// device memory and the stream a shard's worker uses for a search (queries, mask, its k-per-query lists)
+struct ShardStage {
+    rag::Workspace ws;
+    hipStream_t stream = nullptr;
+};
+
 struct rag_multi {
     int dim = 0, kind = 0, metric = 0;
+    std::vector<ShardStage> stage;                  // per shard, on the shard's device
+    rag::Workspace gather;                          // on device[0]: every shard's lists, then the merged answer
+    hipStream_t merge_stream = nullptr;             // on device[0]
+    const char* last_merge = "none";                // where the last search merged the devices' lists
+    int peers = -1;                                 // -1 not probed yet, 1 every device reaches device[0], 0 host merge
     std::vector<rag_index_t*> shard;
     std::vector<int> device;
     std::vector<long long> rows;                    // rows per shard
     std::vector<std::unique_ptr<Worker>> worker;
     std::vector<Piece> pieces;                      // sorted by global
     long long n = 0;
+    bool broken = false;                            // a failed add could not be rolled back on some device
     std::mutex mu;
 };
+
+namespace rag {
+int index_truncate(rag_index* h, long long n);      // api.hip
+}
 
 using rag::fail;
 
@@ -120,6 +141,64 @@ int on_all(rag_multi* h, const std::function<int(int)>& job) {
     }
     return rc == RAG_OK ? RAG_OK : fail(rc, msg);
 }
+
+// One workgroup per query: S lists of k (score, id), each in answer order (best first, ties to the lower id, -1 ids
+// behind the hits).  An entry's place in the merged answer = the entries in front of it in its own list + those of every
+// other list that beat it, found by binary search; entries are distinct in (score, id), so places are too.
+__global__ void multi_merge_kernel(const float* D, const long long* I, int S, long long d_per, long long i_per, int k, int nearest,
+                                   float* Dout, long long* Iout) {
+    const long long q = blockIdx.x;
+    float* dq = Dout + q * k;
+    long long* iq = Iout + q * k;
+    for (int j = threadIdx.x; j < k; j += blockDim.x) {
+        dq[j] = nearest ? FLT_MAX : -FLT_MAX;
+        iq[j] = -1;
+    }
+    __syncthreads();
+    const int total = S * k;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        const int s = e / k, j = e - s * k;
+        const long long id = I[(size_t)s * i_per + q * k + j];
+        if (id < 0) continue;
+        const float sc = D[(size_t)s * d_per + q * k + j];
+        int place = j;
+        for (int t = 0; t < S && place < k; ++t) {
+            if (t == s) continue;
+            const float* dt = D + (size_t)t * d_per + q * k;
+            const long long* it = I + (size_t)t * i_per + q * k;
+            int lo = 0, hi = k;                      // first entry of list t that does not beat (sc, id)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const long long mi = it[mid];
+                const float ms = dt[mid];
+                const bool beats = mi >= 0 && ((nearest ? ms < sc : ms > sc) || (ms == sc && mi < id));
+                if (beats) lo = mid + 1; else hi = mid;
+            }
+            place += lo;
+        }
+        if (place < k) {
+            dq[place] = sc;
+            iq[place] = id;
+        }
+    }
+}
+
+// can every shard's device write into device[0]'s memory?  Probed once; RAG_MULTI_HOST_MERGE=1 keeps the host merge
+int probe_peers(rag_multi* h) {
+    if (h->peers >= 0) return h->peers;
+    const char* e = getenv("RAG_MULTI_HOST_MERGE");
+    int ok = !(e && *e == '1');
+    const int d0 = h->device[0];
+    for (size_t s = 0; ok && s < h->device.size(); ++s) {
+        if (h->device[s] == d0) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, h->device[s], d0) != hipSuccess || !can) ok = 0;
+    }
+    h->peers = ok;
+    return ok;
+}
+
+inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 const Piece* piece_of(const rag_multi* h, long long row) {
     auto it = std::upper_bound(h->pieces.begin(), h->pieces.end(), row, [](long long r, const Piece& p) { return r < p.global; });
@@ -151,6 +230,7 @@ int rag_multi_create(int dim, int metric, int kind, int n_devices, const int* de
         h->device.push_back(device_ids[s]);
         h->rows.push_back(0);
     }
+    h->stage.resize((size_t)n_devices);
     for (int s = 0; s < n_devices; ++s) h->worker.emplace_back(new Worker());
     *out = h.release();
     return RAG_OK;
@@ -159,6 +239,20 @@ int rag_multi_create(int dim, int metric, int kind, int n_devices, const int* de
 int rag_multi_free(rag_multi_t* h) {
     if (!h) return RAG_OK;
     h->worker.clear();                              // joins the threads
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (size_t s = 0; s < h->stage.size(); ++s) {
+        if (!h->stage[s].stream && !h->stage[s].ws.ptr) continue;
+        (void)hipSetDevice(h->device[s]);
+        if (h->stage[s].stream) (void)hipStreamDestroy(h->stage[s].stream);
+        h->stage[s].ws.release();
+    }
+    if (h->gather.ptr || h->merge_stream) {
+        (void)hipSetDevice(h->device[0]);
+        if (h->merge_stream) (void)hipStreamDestroy(h->merge_stream);
+        h->gather.release();
+    }
+    (void)hipSetDevice(prev);
     int rc = RAG_OK;
     for (rag_index_t* idx : h->shard)
         if (int r = rag_index_free(idx)) rc = r;
@@ -172,9 +266,12 @@ int64_t rag_multi_shard_rows(const rag_multi_t* h, int s) {
     return (h && s >= 0 && s < (int)h->shard.size()) ? h->rows[(size_t)s] : 0;
 }
 
+const char* rag_multi_last_merge(const rag_multi_t* h) { return h ? h->last_merge : "none"; }
+
 int rag_multi_train_ivf(rag_multi_t* h, int nlist, const float* centroids, int64_t nsample, const float* sample) {
     if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
     std::lock_guard<std::mutex> lk(h->mu);
+    if (h->broken) return fail(RAG_ERR_INVALID, "a failed add left this index inconsistent: free it");
     // the same centroids on every device: the shards together are one IVF index over all rows
     return on_all(h, [&](int s) { return rag_index_train_ivf(h->shard[(size_t)s], nlist, centroids, nsample, sample); });
 }
@@ -182,6 +279,7 @@ int rag_multi_train_ivf(rag_multi_t* h, int nlist, const float* centroids, int64
 int rag_multi_set_prefilter(rag_multi_t* h, int mode) {
     if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
     std::lock_guard<std::mutex> lk(h->mu);
+    if (h->broken) return fail(RAG_ERR_INVALID, "a failed add left this index inconsistent: free it");
     return on_all(h, [&](int s) { return rag_index_set_prefilter(h->shard[(size_t)s], mode); });
 }
 
@@ -191,6 +289,7 @@ int rag_multi_add(rag_multi_t* h, int64_t n, const float* x, const int64_t* ids)
     if (n == 0) return RAG_OK;
     if (!x) return fail(RAG_ERR_INVALID, "x is NULL");
     std::lock_guard<std::mutex> lk(h->mu);
+    if (h->broken) return fail(RAG_ERR_INVALID, "a failed add left this index inconsistent: free it");
     const int S = (int)h->shard.size();
     // part s of the batch = rows [n*s/S, n*(s+1)/S); every shard keeps explicit ids (the global
     // position when the caller gives none) because its rows are not contiguous in the whole
@@ -203,9 +302,23 @@ int rag_multi_add(rag_multi_t* h, int64_t n, const float* x, const int64_t* ids)
     const int rc = on_all(h, [&](int s) {
         const int64_t b = n * s / S, e = n * (s + 1) / S;
         if (e == b) return (int)RAG_OK;
-        return rag_index_add(h->shard[(size_t)s], e - b, x + (size_t)b * h->dim, ids + b);
+        const int rc_add = rag_index_add(h->shard[(size_t)s], e - b, x + (size_t)b * h->dim, ids + b);
+        // test hook: RAG_TEST_MULTI_FAIL_ADD=<shard> makes that shard report a failure (after it took its rows)
+        const char* inject = getenv("RAG_TEST_MULTI_FAIL_ADD");
+        if (rc_add == RAG_OK && inject && *inject && atoi(inject) == s) return fail(RAG_ERR_OOM, "injected failure");
+        return rc_add;
     });
-    if (rc != RAG_OK) return rc;      // shards that took their part keep it; ntotal of the whole is unchanged
+    if (rc != RAG_OK) {
+        // all or nothing: the shards that took their part give it back (their row counts are the ones recorded
+        // here), so the next add starts from the positions `pieces` knows.  A shard that cannot -- it should
+        // always be able to: nothing has searched the new rows -- leaves the whole index unusable.
+        const std::string why = rag_last_error();
+        for (int s = 0; s < S; ++s)
+            if (rag_index_ntotal(h->shard[(size_t)s]) != h->rows[(size_t)s] &&
+                rag::index_truncate(h->shard[(size_t)s], h->rows[(size_t)s]) != RAG_OK)
+                h->broken = true;
+        return fail(rc, why + (h->broken ? " (and a device could not take its rows back: the index refuses further use)" : ""));
+    }
     for (int s = 0; s < S; ++s) {
         const int64_t b = n * s / S, e = n * (s + 1) / S;
         if (e == b) continue;
@@ -220,6 +333,7 @@ int rag_multi_set_active(rag_multi_t* h, int64_t n, const int64_t* rows, int act
     if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
     if (n < 0 || (n > 0 && !rows)) return fail(RAG_ERR_INVALID, "bad row list");
     std::lock_guard<std::mutex> lk(h->mu);
+    if (h->broken) return fail(RAG_ERR_INVALID, "a failed add left this index inconsistent: free it");
     std::vector<std::vector<int64_t>> local(h->shard.size());
     for (int64_t i = 0; i < n; ++i) {
         const Piece* p = piece_of(h, rows[i]);
@@ -236,6 +350,7 @@ int rag_multi_reconstruct(rag_multi_t* h, int64_t n, const int64_t* rows, float*
     if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
     if (n < 0 || (n > 0 && (!rows || !out))) return fail(RAG_ERR_INVALID, "bad row list");
     std::lock_guard<std::mutex> lk(h->mu);
+    if (h->broken) return fail(RAG_ERR_INVALID, "a failed add left this index inconsistent: free it");
     const size_t S = h->shard.size();
     std::vector<std::vector<int64_t>> local(S), where(S);
     for (int64_t i = 0; i < n; ++i) {
@@ -265,6 +380,7 @@ int rag_multi_search(rag_multi_t* h, int64_t nq, const float* q, int k, float mi
     if (nq == 0) return RAG_OK;
     if (!q || !D || !I) return fail(RAG_ERR_INVALID, "NULL buffer");
     std::lock_guard<std::mutex> lk(h->mu);
+    if (h->broken) return fail(RAG_ERR_INVALID, "a failed add left this index inconsistent: free it");
     const size_t S = h->shard.size();
     // the caller's mask counts rows in insertion order: cut it into the shards' own orders
     std::vector<std::vector<uint8_t>> mask(S);
@@ -273,6 +389,66 @@ int rag_multi_search(rag_multi_t* h, int64_t nq, const float* q, int k, float mi
         for (const Piece& p : h->pieces) memcpy(mask[(size_t)p.shard].data() + p.local, row_mask + p.global, (size_t)p.count);
     }
     const size_t per = (size_t)nq * (size_t)k;
+    const bool nearest = h->metric == RAG_METRIC_L2;
+    if (probe_peers(h)) {
+        // ---- the lists stay on the devices: peer copies into device[0], one merge kernel, one copy out ----
+        const int d0 = h->device[0];
+        const size_t db = al256(per * sizeof(float)), ib = al256(per * sizeof(int64_t));
+        int prev = 0;
+        RAG_HIP_CHECK(hipGetDevice(&prev));
+        struct Restore { int p; ~Restore() { (void)hipSetDevice(p); } } restore{prev};
+        RAG_HIP_CHECK(hipSetDevice(d0));
+        if (int rc = h->gather.ensure(S * (db + ib) + db + ib)) return rc;
+        if (!h->merge_stream) RAG_HIP_CHECK(hipStreamCreateWithFlags(&h->merge_stream, hipStreamNonBlocking));
+        char* g = static_cast<char*>(h->gather.ptr);
+        float* gD = reinterpret_cast<float*>(g);                                   // [S][db]
+        int64_t* gI = reinterpret_cast<int64_t*>(g + S * db);                      // [S][ib]
+        float* oD = reinterpret_cast<float*>(g + S * (db + ib));
+        int64_t* oI = reinterpret_cast<int64_t*>(g + S * (db + ib) + db);
+        const int rc = on_all(h, [&](int s) {
+            const int dev = h->device[(size_t)s];
+            RAG_HIP_CHECK(hipSetDevice(dev));
+            ShardStage& st = h->stage[(size_t)s];
+            if (!st.stream) RAG_HIP_CHECK(hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking));
+            const size_t qb = al256((size_t)nq * h->dim * sizeof(float));
+            const size_t mb = row_mask ? al256((size_t)h->rows[(size_t)s]) : 0;
+            if (int r = st.ws.ensure(qb + db + ib + mb + 256)) return r;
+            char* w = static_cast<char*>(st.ws.ptr);
+            float* q_dev = reinterpret_cast<float*>(w);
+            float* D_dev = reinterpret_cast<float*>(w + qb);
+            int64_t* I_dev = reinterpret_cast<int64_t*>(w + qb + db);
+            uint8_t* m_dev = row_mask ? reinterpret_cast<uint8_t*>(w + qb + db + ib) : nullptr;
+            RAG_HIP_CHECK(hipMemcpyAsync(q_dev, q, (size_t)nq * h->dim * sizeof(float), hipMemcpyHostToDevice, st.stream));
+            if (row_mask && h->rows[(size_t)s] > 0)
+                RAG_HIP_CHECK(hipMemcpyAsync(m_dev, mask[(size_t)s].data(), (size_t)h->rows[(size_t)s], hipMemcpyHostToDevice, st.stream));
+            // (a shard without rows answers with empty lists by itself)
+            if (int r = rag_index_search_device(h->shard[(size_t)s], nq, q_dev, k, min_score, nprobe, m_dev, D_dev, I_dev, st.stream)) return r;
+            float* dst_d = reinterpret_cast<float*>(reinterpret_cast<char*>(gD) + (size_t)s * db);
+            int64_t* dst_i = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(gI) + (size_t)s * ib);
+            if (dev == d0) {
+                RAG_HIP_CHECK(hipMemcpyAsync(dst_d, D_dev, per * sizeof(float), hipMemcpyDeviceToDevice, st.stream));
+                RAG_HIP_CHECK(hipMemcpyAsync(dst_i, I_dev, per * sizeof(int64_t), hipMemcpyDeviceToDevice, st.stream));
+            } else {
+                RAG_HIP_CHECK(hipMemcpyPeerAsync(dst_d, d0, D_dev, dev, per * sizeof(float), st.stream));
+                RAG_HIP_CHECK(hipMemcpyPeerAsync(dst_i, d0, I_dev, dev, per * sizeof(int64_t), st.stream));
+            }
+            RAG_HIP_CHECK(hipStreamSynchronize(st.stream));
+            return (int)RAG_OK;
+        });
+        if (rc != RAG_OK) return rc;
+        hipLaunchKernelGGL(multi_merge_kernel, dim3((unsigned)nq), dim3(256), 0, h->merge_stream, gD,
+                           reinterpret_cast<const long long*>(gI), (int)S, (long long)(db / sizeof(float)),
+                           (long long)(ib / sizeof(int64_t)), k, nearest ? 1 : 0, oD,
+                           reinterpret_cast<long long*>(oI));
+        RAG_HIP_CHECK(hipGetLastError());
+        RAG_HIP_CHECK(hipMemcpyAsync(D, oD, per * sizeof(float), hipMemcpyDeviceToHost, h->merge_stream));
+        RAG_HIP_CHECK(hipMemcpyAsync(I, oI, per * sizeof(int64_t), hipMemcpyDeviceToHost, h->merge_stream));
+        RAG_HIP_CHECK(hipStreamSynchronize(h->merge_stream));
+        h->last_merge = "device";
+        return RAG_OK;
+    }
+    // ---- a device cannot reach device[0] peer to peer: lists through the host, merged here ----
+    h->last_merge = "host";
     std::vector<float> Ds(S * per);
     std::vector<int64_t> Is(S * per);
     const int rc = on_all(h, [&](int s) {
@@ -287,7 +463,6 @@ int rag_multi_search(rag_multi_t* h, int64_t nq, const float* q, int k, float mi
     });
     if (rc != RAG_OK) return rc;
     // k-way merge of S sorted lists per query: score descending (L2: distance ascending), ties to the lower id
-    const bool nearest = h->metric == RAG_METRIC_L2;
     std::vector<size_t> head(S);
     for (int64_t qi = 0; qi < nq; ++qi) {
         std::fill(head.begin(), head.end(), (size_t)0);

@@ -14,6 +14,7 @@
 // written by the Python layer).
 #include <stdio.h>
 #include <string.h>
+#include <sys/stat.h>
 
 #include <algorithm>
 #include <vector>
@@ -112,6 +113,8 @@ extern "C" int rag_index_save(rag_index_t* h, const char* path) {
     return RAG_OK;
 }
 
+static int load_body(FILE* f, const SnapHeader& hd, bool ivf, int device, rag_index_t** out);
+
 extern "C" int rag_index_load(const char* path, int device, rag_index_t** out) {
     if (!path || !out) return fail(RAG_ERR_INVALID, "NULL argument");
     *out = nullptr;
@@ -125,6 +128,28 @@ extern "C" int rag_index_load(const char* path, int device, rag_index_t** out) {
         return fail(RAG_ERR_INVALID, "corrupt snapshot header");
     if (hd.metric != RAG_METRIC_IP && hd.metric != RAG_METRIC_COSINE && hd.metric != RAG_METRIC_L2) return fail(RAG_ERR_INVALID, "snapshot names an unknown metric");
     if (hd.metric == RAG_METRIC_L2 && ivf) return fail(RAG_ERR_INVALID, "corrupt snapshot header");
+    // the header's counts size every buffer below: hold them to the limits of an index and to the length of the file first
+    if (hd.dim > 65536 || hd.n > 0x7FFFFFF0LL || hd.nlist > (1 << 22)) return fail(RAG_ERR_INVALID, "corrupt snapshot header (counts out of range)");
+    {
+        struct stat st;
+        if (fstat(fileno(f), &st) != 0) return fail(RAG_ERR_INVALID, "cannot stat the snapshot");
+        unsigned long long need = sizeof(hd) + (unsigned long long)hd.n * hd.dim * sizeof(float);
+        if (ivf) need += (unsigned long long)hd.nlist * hd.dim * sizeof(float) + (unsigned long long)hd.n * sizeof(int);
+        if (hd.flags & 1) need += (unsigned long long)hd.n * sizeof(long long);
+        if (hd.flags & 2) need += (unsigned long long)hd.n;
+        if ((unsigned long long)st.st_size < need)
+            return fail(RAG_ERR_INVALID, "truncated snapshot: " + std::to_string((long long)st.st_size) + " bytes, the header needs " + std::to_string(need));
+    }
+    try {
+        return load_body(f, hd, ivf, device, out);
+    } catch (const std::bad_alloc&) {
+        return fail(RAG_ERR_OOM, "out of host memory while loading the snapshot");
+    } catch (const std::exception& e) {
+        return fail(RAG_ERR_INVALID, std::string("snapshot load failed: ") + e.what());
+    }
+}
+
+static int load_body(FILE* f, const SnapHeader& hd, bool ivf, int device, rag_index_t** out) {
     rag_index* h = nullptr;
     // rows in the file are already normalised for COSINE: load them as they are, then restore the metric
     // (L2 rows are stored as given; adding them rebuilds their extra column)

@@ -339,6 +339,12 @@ class MultiDeviceIndex:
     def __len__(self) -> int:
         return int(lib.rag_multi_ntotal(self._h))
 
+    @property
+    def last_merge(self) -> str:
+        """Where the last search merged the devices' lists: 'device' (peer copies into the first device and
+        one merge kernel there) or 'host' (a device cannot reach the first one peer to peer)."""
+        return (lib.rag_multi_last_merge(self._h) or b"").decode()
+
     def shard_rows(self) -> List[int]:
         return [int(lib.rag_multi_shard_rows(self._h, s)) for s in range(len(self.devices))]
 

@@ -238,15 +238,24 @@ class PooledCollections:
         return out
 
     def chunk_ids_distinct(self, name: str) -> bool:
-        """True when no two live points of the collection show the same chunk id in their
-        result dictionaries (kept until the pool changes)."""
+        """True when every live point of the collection shows a chunk id of its own in its result
+        dictionary (kept until the pool changes).  A payload that carries an explicit empty / None
+        ``chunk_id`` makes it False: such a hit has no key to fuse under and the reference drops it
+        BEFORE the cut to ``limit`` (vector_db/search_manager.py:899-901), which a device-side cut
+        cannot reproduce -- those collections take the list fusion on the host."""
         hit = self._distinct_cache.get(name)
         if hit is None or hit[0] != self._version:
             rows = self._rows.get(name, {})
-            seen = {(self.payloads[r] or {}).get("chunk_id") or str(self.point_ids[r]) for r in rows.values()}
+            seen, ok = set(), True
+            for r in rows.values():
+                payload = self.payloads[r] or {}
+                if "chunk_id" in payload and not payload["chunk_id"]:
+                    ok = False
+                    break
+                seen.add(payload.get("chunk_id") or str(self.point_ids[r]))
             if len(self._distinct_cache) >= 65536:
                 self._distinct_cache.clear()
-            self._distinct_cache[name] = hit = (self._version, len(seen) == len(rows))
+            self._distinct_cache[name] = hit = (self._version, ok and len(seen) == len(rows))
         return hit[1]
 
     def fused_search(self, names: Sequence[str], query_vectors, weights: Sequence[float], per_limit: int, limit: int,

@@ -6,7 +6,8 @@ where the CPU oracle cannot run: size-independent properties of an exact top-k.
 * lists are sorted, ids unique and in range;
 * the two independent kernels (HBM scan, MFMA GEMM) return the same ids;
 * top-k(whole) == merge(top-k(halves)) through the segment search;
-* no row of a random 200k-row sample beats the k-th returned score.
+* no row of a random 200k-row sample beats the k-th returned score;
+* the 4096-query batch the headline rate is quoted on, checked whole (see fullsize_checks.py).
 """
 import numpy as np
 import pytest
@@ -14,6 +15,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 N, D, K = 10_000_000, 768, 10
+BIG = 4096
+EXTRA = {}
 
 
 @pytest.fixture(scope="module")
@@ -43,6 +46,13 @@ def corpus():
             dup = centre[None, :] + 0.3 / D ** 0.5 * torch.randn((count, D), generator=g, device=dev)
             X[rows] = dup / dup.norm(dim=1, keepdim=True)
     X[torch.from_numpy(planted).to(dev)] = Q                # (a cluster row may have landed on a planted one)
+    # queries 64 .. 4095 of the large batch get a planted copy too (rows no earlier planting uses)
+    Qbig = make_queries(torch, BIG, D, dev)                  # the first 64 equal Q (same seed)
+    more = np.setdiff1d(rng.choice(N, 2 * BIG, replace=False), planted)[:BIG - 64]
+    rng.shuffle(more)
+    X[torch.from_numpy(more).to(dev)] = Qbig[64:]
+    X[torch.from_numpy(planted).to(dev)] = Q
+    EXTRA["Qbig"], EXTRA["planted_big"] = Qbig, np.concatenate([planted, more])
     idx = DeviceIndex(D, metric="ip")
     idx.adopt(X)
     yield torch, X, Q, idx, planted
@@ -127,6 +137,25 @@ def test_every_gemm_shape_agrees_with_the_scan(corpus):
             if qi < nq:
                 assert np.array_equal(Ig[qi], Is), (nq, qi)
                 assert np.allclose(Dg[qi], Ds, rtol=1e-5, atol=1e-6)
+
+
+def test_batch_4096_at_full_size(corpus):
+    """The shape the batch-4096 rate is quoted on: 4096 queries x 10M x 768 through the selecting
+    matrix-core kernel (16 query blocks x row ranges).  Every list is checked on the device (sorted,
+    unique, fp64 re-score, planted rows first); the first and last query of every 256-query block and
+    a few more are compared with single-query scans; no sampled row beats a k-th score."""
+    torch, X, Q, idx, planted = corpus
+    import fullsize_checks as fc
+    Qbig, planted_big = EXTRA["Qbig"], EXTRA["planted_big"]
+    assert torch.equal(Qbig[:64], Q)
+    Dg, Ig = idx.search(Qbig, K)
+    assert idx.last_path == "gemm"
+    fc.check_batch_answer(torch, X, Qbig, Dg, Ig, planted_big)
+    fc.check_against_single_scans(torch, idx, Qbig, Dg, Ig, fc.block_edges(BIG), K)
+    fc.check_no_sampled_row_beats_the_kth(torch, X, Qbig, Dg, Ig, [0, 255, 256, 1000, 2047, 2048, 4095])
+    # a second call returns the same bits (the candidate buffers and thresholds start clean)
+    D2, I2 = idx.search(Qbig, K)
+    assert torch.equal(I2, Ig) and torch.equal(D2, Dg)
 
 
 def test_bf16_first_pass_returns_the_fp32_answer(corpus):

@@ -270,3 +270,34 @@ def test_batched_pipeline_equals_the_oracle_per_query():
         _check_batch(idx, X, Q, topn, bm_rows, bm_scores, to_rows, to_id, **kw)
     for idx in (flat_ids, flat_base, iv):
         idx.close()
+
+
+def test_batched_pipeline_on_an_ivf_index_that_repacks_inside_the_call():
+    """add -> search (the rows are packed by list) -> add more -> the batch call as the first search after the second add:
+    that search re-packs the rows (a new row buffer, a new insertion -> storage map) while the call is being built, and the
+    fusion / MMR stages must read the vectors through the buffers of AFTER the re-pack.  Both adds are shuffled so the
+    storage order differs from the insertion order, and the candidates come from both."""
+    from rag_amd import DeviceIndex
+    rng = np.random.default_rng(33)
+    n, d, nlist = 40_000, 128, 24
+    X, cent = _clustered(rng, n, d, ncl=30)
+    X = X[rng.permutation(n)]
+    C0 = X[rng.choice(n, nlist, replace=False)].copy()
+    iv = DeviceIndex(d, metric="ip", kind="ivf")
+    iv.train_ivf(nlist, centroids=C0)
+    first = 25_000
+    iv.add(X[:first])
+    q0 = (cent[0] / np.linalg.norm(cent[0])).astype(np.float32)
+    iv.search(q0[None, :], 10, nprobe=4)                             # packs the first 25 000 rows
+    iv.add(X[first:])                                                # 15 000 rows wait at the tail
+    nq, topn, nb = 7, 120, 30
+    Q = np.stack([cent[i] / np.linalg.norm(cent[i]) for i in range(nq)]).astype(np.float32)
+    Q += 0.02 * rng.standard_normal(Q.shape).astype(np.float32)
+    bm_rows = rng.integers(0, n, (nq, nb)).astype(np.int64)
+    bm_scores = rng.gamma(2.0, 2.0, size=(nq, nb))
+    _check_batch(iv, X, Q, topn, bm_rows, bm_scores, lambda I: I, lambda r: r, nprobe=8)
+    iv.add(X[:500] * np.float32(0.5))                                # and once more, with a larger pack behind it
+    X2 = np.concatenate([X, X[:500] * np.float32(0.5)])
+    bm_rows2 = rng.integers(0, n + 500, (nq, nb)).astype(np.int64)
+    _check_batch(iv, X2, Q, topn, bm_rows2, bm_scores, lambda I: I, lambda r: r, nprobe=8)
+    iv.close()

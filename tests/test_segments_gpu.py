@@ -287,3 +287,41 @@ def test_pool_backup_restore_and_last_duplicate_wins(tmp_path):
     assert back.compact() == pool.dead_rows()                    # a restored pool vacuums like the original
     back.close()
     pool.close()
+
+
+def test_a_payload_with_an_empty_chunk_id_keeps_the_host_fusion():
+    """A payload that carries an explicit empty chunk_id: the reference skips such a hit before it cuts to
+    `limit` (vector_db/search_manager.py:899-901, :928-932), so a full list still comes back.  The device-side
+    cut cannot do that; collections with such a payload take the list fusion, and the answers equal the
+    per-collection manager's."""
+    from rag_amd.schemas import SearchFilters
+    from rag_amd.search_engine import HipSearchEngine
+    from rag_amd.storage_manager import VectorStorageManager
+    run = asyncio.get_event_loop().run_until_complete
+    rng = np.random.default_rng(5)
+    d = 64
+    plain, pooled = VectorStorageManager(), VectorStorageManager(pooled=True)
+    Q = _unit(rng, 3, d)
+    for doc in (1, 2):
+        n = 40
+        content = _unit(rng, n, d)
+        content[:6] = Q[0] + 0.01 * rng.standard_normal((6, d)).astype(np.float32)      # the best hits of query 0 ...
+        ids = [f"doc_{doc}_chunk_{i}" for i in range(n)]
+        meta = [{"document_id": doc, "text": f"{doc}/{i}", "user_id": 7} for i in range(n)]
+        if doc == 2:
+            meta[0]["chunk_id"] = ""                                                     # ... one of which has no chunk id
+            meta[3]["chunk_id"] = None
+        for m in (plain, pooled):
+            assert run(m.create_index(f"doc_{doc}", d))
+            assert run(m.add_vectors(f"doc_{doc}", content.tolist(), content.tolist(), meta, ids)) == ids
+    strat = [("full_query", Q[0].tolist(), 0.4), ("concepts", Q[1].tolist(), 0.6), ("expanded", Q[2].tolist(), 0.3)]
+    pool = pooled.search_optimizers["doc_1_content"].pool
+    assert pool.chunk_ids_distinct("doc_1_content") and not pool.chunk_ids_distinct("doc_2_content")
+    for docs, path in (([1], "segments-fused"), ([1, 2], "segments"), ([2], "segments")):
+        filt = SearchFilters(user_id=7, document_ids=docs, min_score=None)
+        a, b = (run(HipSearchEngine(m).semantic_search(strat, filt, 8)) for m in (pooled, plain))
+        assert pool.index.last_path == path
+        assert len(a) == 8 and all(r.chunk_id for r in a)
+        assert [(r.document_id, r.chunk_id) for r in a] == [(r.document_id, r.chunk_id) for r in b]
+    run(plain.cleanup())
+    run(pooled.cleanup())
