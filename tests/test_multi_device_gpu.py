@@ -96,7 +96,7 @@ def test_device_merge_equals_host_merge(monkeypatch):
             for lo in range(0, n, 6000):                    # four adds: a shard holds four separate id ranges
                 m.add(X[lo:lo + 6000])
             res = []
-            for k, kw in ((10, {}), (40, {"min_score": 0.2 if metric == "ip" else 1.6}), (1024, {}), (3, {"row_mask": (np.arange(n) % 3 > 0).astype(np.uint8)})):
+            for k, kw in ((10, {}), (40, {"min_score": 0.38 if metric == "ip" else 1.24}), (1024, {}), (3, {"row_mask": (np.arange(n) % 3 > 0).astype(np.uint8)})):
                 res.append(m.search(Q, k, **kw))
                 assert m.last_merge == ("host" if mode == "1" else "device")
             got[mode] = res
@@ -106,7 +106,7 @@ def test_device_merge_equals_host_merge(monkeypatch):
         D, I = got["0"][0]
         assert I[0, :10].tolist() == list(range(5, 10_000, 1000))      # equal scores: ids ascending
         D, I = got["0"][1]
-        assert (I == -1).any() and (I[:, 0] >= 0).all()                 # the threshold leaves short lists, padded
+        assert (I == -1).any() and (I >= 0).any()                       # the threshold leaves short lists, padded
 
 
 def test_a_failed_add_is_taken_back_on_every_device(monkeypatch):
