@@ -13,7 +13,7 @@ import re
 import sys
 
 HOT = ("gemm_topk_kernel", "narrow_topk_kernel", "flat_scan_kernel", "merge_keys_kernel", "merge_keys_small_kernel",
-       "mmr_simmat_kernel", "rescore_select_kernel", "direct_scores_kernel", "direct_select_kernel")
+       "mmr_simmat_kernel", "rescore_select_kernel", "direct_scores_kernel", "direct_select_kernel", "ivf_lists_kernel")
 # Known and bounded: bytes of scratch per lane a kernel may use.  The fp32 256 x 256 shape sits at
 # the 256-register limit of two waves per SIMD (128 accumulators, two fragment sets, loader
 # addresses); the allocator parks loader addresses and the work-item bounds in scratch and reloads

@@ -55,6 +55,7 @@
 #include <algorithm>
 
 #include "index.h"
+#include "ivf_lists.h"
 #include "topk_keys.h"
 
 namespace rag {
@@ -1355,6 +1356,8 @@ __global__ void lm_fill_kernel(const long long* lists, long long npairs, int npr
 constexpr int LM_GRID = 512;      // persistent workgroups of the list-major scan (2 per CU)
 
 static size_t lm_align(size_t b) { return (b + 255) & ~(size_t)255; }
+// candidate buffers of whichever of the two list-scan kernels runs
+static size_t lm_cand_bytes() { return std::max((size_t)LM_GRID * 32 * gemm_capq(256, 32) * sizeof(u64), lm_align(ivf_lists_cand_bytes())); }
 
 bool ivf_listmajor_supported(const rag_index* h, long long nq, int k, int nprobe) {
     static const int on = env_int_g("RAG_IVF_LISTMAJOR", 1);
@@ -1369,7 +1372,7 @@ bool ivf_listmajor_supported(const rag_index* h, long long nq, int k, int nprobe
 size_t ivf_listmajor_workspace(const rag_index* h, long long nq, int k, int nprobe) {
     const size_t nlist = (size_t)h->ivf.nlist, npairs = (size_t)nq * nprobe;
     return 4 * lm_align(nlist * 4) + 256 + lm_align((std::min(nlist, npairs) + npairs / 32 + 64) * 4) + 2 * lm_align(npairs * 4) +
-           (size_t)LM_GRID * 32 * gemm_capq(256, 32) * sizeof(u64) + lm_align(npairs * k * sizeof(u64)) + lm_align((size_t)nq * 4);
+           lm_cand_bytes() + lm_align(npairs * k * sizeof(u64)) + lm_align((size_t)nq * 4);
 }
 
 int ivf_listmajor_scan(rag_index* h, long long nq, const float* qbuf, int k, float min_score, int nprobe,
@@ -1388,18 +1391,57 @@ int ivf_listmajor_scan(rag_index* h, long long nq, const float* qbuf, int k, flo
     int* task_list = reinterpret_cast<int*>(w);          w += lm_align((std::min(nlist, npairs) + npairs / 32 + 64) * 4);
     int* pair_q = reinterpret_cast<int*>(w);             w += lm_align(npairs * 4);
     int* pair_slot = reinterpret_cast<int*>(w);          w += lm_align(npairs * 4);
-    u64* cand = reinterpret_cast<u64*>(w);               w += (size_t)LM_GRID * 32 * gemm_capq(256, 32) * sizeof(u64);
+    u64* cand = reinterpret_cast<u64*>(w);               w += lm_cand_bytes();
     u64* part = reinterpret_cast<u64*>(w);               w += lm_align(npairs * k * sizeof(u64));
     unsigned int* gthr = reinterpret_cast<unsigned int*>(w);
     static const int share_thr = env_int_g("RAG_IVF_SHARE_THR", 1);                // measurement knob
     RAG_HIP_CHECK(hipMemsetAsync(gthr, 0, (size_t)nq * 4, s));
     RAG_HIP_CHECK(hipMemsetAsync(cnt, 0, 2 * lm_align(nlist * 4), s));          // cnt and fill
+    RAG_HIP_CHECK(hipMemsetAsync(total, 0, 256, s));                            // [0] work items (lm_plan_kernel), [1] the work queue's head
     RAG_HIP_CHECK(hipMemsetAsync(part, 0, npairs * k * sizeof(u64), s));        // pairs without rows stay empty
     const int pb = (int)std::min<size_t>((npairs + 255) / 256, 4096);
     hipLaunchKernelGGL(lm_count_kernel, dim3(pb), dim3(256), 0, s, coarse_lists, (long long)npairs, cnt);
     hipLaunchKernelGGL(lm_plan_kernel, dim3(1), dim3(1024), 0, s, cnt, (int)nlist, v.list_begin_dev, pair_begin, task_begin, task_list, total);
     hipLaunchKernelGGL(lm_fill_kernel, dim3(pb), dim3(256), 0, s, coarse_lists, (long long)npairs, nprobe, pair_begin, fill, pair_q, pair_slot);
     RAG_HIP_CHECK(hipGetLastError());
+    MergeArgs m = {};
+    m.keys = part;
+    m.per_query = (long long)nprobe * k;
+    m.k = k;
+    m.cap = merge_cap(m.per_query, k);
+    m.min_score = min_score;
+    m.row_ids = h->ids_dev;
+    m.id_base = h->id_base;
+    m.rows_out = h->merge_rows_out;
+    m.D = D;
+    m.I = I;
+    if (ivf_lists_kernel_ok(h, k)) {
+        // the register-streaming kernel (ivf_lists.hip): 16-query column blocks, work items from a device queue
+        ListScanArgs ls = {};
+        ls.X = h->X;
+        ls.Q = qbuf;
+        ls.mask = mask;            // both masks count rows in insertion order, like the keys
+        ls.mask2 = mask2;
+        ls.cand = cand;
+        ls.part = part;
+        ls.gthr = gthr;
+        ls.counters = total;
+        ls.task_list = task_list;
+        ls.task_begin = task_begin;
+        ls.pair_begin = pair_begin;
+        ls.pair_cnt = cnt;
+        ls.pair_q = pair_q;
+        ls.pair_slot = pair_slot;
+        ls.list_begin = v.list_begin_dev;
+        ls.row_alias = v.orig_dev;
+        ls.ld = h->ld;
+        ls.k = k;
+        if (int rc = profile_begin(h, s)) return rc;
+        if (int rc = ivf_lists_launch(ls, s)) return rc;
+        if (int rc = profile_end(h, s)) return rc;
+        RAG_HIP_CHECK(launch_merge_keys(m, nq, s));
+        return RAG_OK;
+    }
     GemmArgs a = {};
     a.X = h->X;
     a.Q = qbuf;
@@ -1437,17 +1479,6 @@ int ivf_listmajor_scan(rag_index* h, long long nq, const float* qbuf, int k, flo
         RAG_HIP_CHECK(hipGetLastError());
     }
     if (int rc = profile_end(h, s)) return rc;
-    MergeArgs m = {};
-    m.keys = part;
-    m.per_query = (long long)nprobe * k;
-    m.k = k;
-    m.cap = merge_cap(m.per_query, k);
-    m.min_score = min_score;
-    m.row_ids = h->ids_dev;
-    m.id_base = h->id_base;
-    m.rows_out = h->merge_rows_out;
-    m.D = D;
-    m.I = I;
     RAG_HIP_CHECK(launch_merge_keys(m, nq, s));
     return RAG_OK;
 }
