@@ -7,15 +7,16 @@
 // the work items do, which halves their matrix-core time (with 32 columns always multiplied that time is about
 // what the bytes need at the HBM peak, so both roofs bound the 256 x 32 LDS-tiled shape this replaces).
 //
-// Structure (the register-streaming scheme of narrow_topk.hip, with the queries streamed as well).  The four waves
-// of a workgroup split a list's rows into four contiguous quarters and never synchronise while they stream.  A wave
-// walks its rows in tiles of 32; per K step (32 floats) it fetches 32 rows x 128 contiguous bytes (four wave
-// instructions of 8 rows x 128 B, non-temporal) and its B fragments -- the work item's queries, gathered by index,
-// straight from L2 in fragment order -- into a ring of DEPTH register sets, so DEPTH - 1 steps stay in flight per
-// wave while one is multiplied; a landed step goes through the wave-private 4 KiB LDS transposer (ds_write_b128 rows,
-// ds_read_b128 fragments, 16-byte chunks XOR-swizzled by row pair: conflict free both ways).  Loads return in issue
-// order per wave, so the queries ride in the same ring as the rows: waiting for a step's B fragments then waits
-// for nothing younger than the step itself.
+// Structure (the register-streaming scheme of narrow_topk.hip, with the queries gathered per work item).  The four
+// waves of a workgroup split a list's rows into four contiguous quarters.  A wave walks its rows in tiles of 32; per
+// K step (32 floats) it fetches 32 rows x 128 contiguous bytes (four wave instructions of 8 rows x 128 B,
+// non-temporal) into a ring of DEPTH register sets, so DEPTH - 1 steps stay in flight per wave while one is
+// multiplied; a landed step goes through the wave-private 4 KiB LDS transposer (ds_write_b128 rows, ds_read_b128
+// fragments, 16-byte chunks XOR-swizzled by row pair: conflict free both ways).  The queries of the work item are
+// shared: per rotation of four K steps each wave fetches ONE step's query image (up to 32 gathered queries x 128 B,
+// coalesced, from L2), one rotation ahead, writes it to LDS in the transposer's layout, and after one LDS-only
+// barrier per rotation (the row loads stay in flight across it) every wave reads its B fragments from the four
+// images -- a quarter of the query traffic of four independent waves, and no query registers in the ring.
 //
 // Selection (k <= 32), per wave and pair: a 64-key candidate buffer in global memory (L2) and a threshold in LDS; a
 // query's lists share one threshold word (atomicMax on ordered-float bits), so a pair starts from the k-th best
@@ -51,30 +52,32 @@ constexpr int LS_CAP = LS_TRIG + LS_TILE;   // 64: one key per lane when sorted
 #define RAG_LISTS_DIAG 0
 #endif
 // K steps in the register ring for work items of one / two column blocks (measurement knobs)
-// 1: the four waves of a workgroup meet at a barrier after every ring rotation (measurement knob)
-#ifndef RAG_LISTS_LOCKSTEP
-#define RAG_LISTS_LOCKSTEP 0
-#endif
 #ifndef RAG_LISTS_DEPTH1
-#define RAG_LISTS_DEPTH1 4
+#define RAG_LISTS_DEPTH1 8
 #endif
 #ifndef RAG_LISTS_DEPTH2
 #define RAG_LISTS_DEPTH2 4
 #endif
 
-// one K step of a wave as loaded: rows [row group][8-row half], queries [16-float half of the step][column block]
-template <int NCB>
+constexpr int LS_ROT = 4;              // K steps per rotation of the query images (one step's image per wave)
+
+// one K step of a wave's rows as loaded: [row group][8-row half], 16 bytes per lane each
 struct LsStep {
     f4 a[2][2];
-    f4 b[2][NCB];
 };
 
-// The rows [r_lo, r_hi) of one list against the work item's queries, by one wave.  tp: the wave's transposer;
-// my_thr / my_cnt / my_cand: its thresholds, counts and candidate buffers for the item's (up to 32) pairs.
+// workgroup barrier that orders LDS accesses only: the register ring's loads stay in flight across it
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// The rows [r_lo, r_hi) of one list against the work item's queries, by one wave, in step with the other waves
+// of its workgroup: every wave walks T tiles (a wave with fewer rows re-reads its last ones and selects nothing).
+// tp: the wave's transposer; bq: the workgroup's query images [2][LS_ROT][256 f4]; my_thr / my_cnt / my_cand: the
+// wave's thresholds, counts and candidate buffers for the item's (up to 32) pairs.
 template <int NCB, int DEPTH>
-__device__ __forceinline__ void ls_scan_rows(const ListScanArgs& a, f4* tp, float* my_thr, int* my_cnt, u64* my_cand,
-                                             const int* pq, int m_valid, long long r_lo, long long r_hi, long long t_all, bool live, int lane) {
-    static_assert(DEPTH >= 4 && (DEPTH & 1) == 0, "the fragment parity must repeat per ring rotation");
+__device__ __forceinline__ void ls_scan_rows(const ListScanArgs& a, f4* tp, f4* bq, float* my_thr, int* my_cnt, u64* my_cand,
+                                             const int* pq, int m_valid, long long r_lo, long long r_hi, long long T, bool live,
+                                             int wave, int lane) {
+    static_assert(DEPTH % LS_ROT == 0, "the row ring turns in whole rotations of the query images");
     const int r16 = lane & 15, kq = lane >> 4;
     const int lrow = lane >> 3, lchunk = lane & 7;      // as loaded: row within an 8-row half, 16-byte chunk
     const int k = a.k;
@@ -82,33 +85,58 @@ __device__ __forceinline__ void ls_scan_rows(const ListScanArgs& a, f4* tp, floa
     const int steps = a.ld / 32;                        // K steps per tile, a multiple of DEPTH
     const f4* X4 = reinterpret_cast<const f4*>(a.X);
     const f4* Q4 = reinterpret_cast<const f4*>(a.Q);
-    int wr_off[2], rd_off[2];                           // f4 units inside one row group's image
+    int wr_off[2], rd_off[2];                           // f4 units inside one 16-row image
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
         const int ru = hh * 8 + lrow;
         wr_off[hh] = ru * 8 + (lchunk ^ ((ru >> 1) & 7));
         rd_off[hh] = r16 * 8 + ((4 * hh + kq) ^ ((r16 >> 1) & 7));      // hh = which 16 floats of the step (m)
     }
-    // B fragments: lane (c = r16, kq) holds Q[query of column c][32 step + 16 m + 4 kq .. + 3]; surplus columns
-    // repeat the last pair's query and are never selected
-    const f4* qp[NCB];
-    int qg[NCB];                                        // the column's query (for the shared threshold)
+    // ---- queries: one K step of all columns is an image like the transposer's (16 columns per group, same swizzle);
+    // wave w fetches the image of step 4 r + w of every rotation r -- coalesced, 8 queries x 128 contiguous bytes
+    // per wave instruction -- one rotation ahead, and every wave reads its B fragments from the images.  Surplus
+    // columns repeat the last pair's query and are never selected.
+    const f4* bp[2 * NCB];
+#pragma unroll
+    for (int i = 0; i < 2 * NCB; ++i) {
+        const int ql = 8 * i + lrow;
+        bp[i] = Q4 + (size_t)pq[ql < m_valid ? ql : m_valid - 1] * ld4 + lchunk;
+    }
+    int qg[NCB];                                        // the query of this lane's column (for the shared threshold)
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
         const int ql = cb * 16 + r16;
         qg[cb] = pq[ql < m_valid ? ql : m_valid - 1];
-        qp[cb] = Q4 + (size_t)qg[cb] * ld4 + kq;
     }
-    // (lockstep builds: every wave of the workgroup walks the same number of tiles, t_all, so that they meet at the barriers)
-    const long long T = RAG_LISTS_LOCKSTEP ? t_all : (r_hi - r_lo + LS_TILE - 1) / LS_TILE;
-    // rows past the end repeat the last row; tiles past the range repeat the last tile: loaded, never used
+    int bs = wave;                                      // K step (within a tile) of the image this wave fetches next
+    f4 share[2 * NCB];
+    auto fetch_b = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2 * NCB; ++i) share[i] = (RAG_LISTS_DIAG & 128) ? (f4){1.f, 2.f, 3.f, 4.f} : bp[i][bs * 8];
+        bs += LS_ROT;
+        if (bs >= steps) bs -= steps;
+    };
+    auto write_b = [&](int buf) {
+        f4* dst = bq + (buf * LS_ROT + wave) * 256;
+#pragma unroll
+        for (int i = 0; i < 2 * NCB; ++i) dst[(i >> 1) * 128 + wr_off[i & 1]] = share[i];
+    };
+    f4 bf[2][2][NCB];                                   // [parity][m][column block]
+    auto read_b = [&](int buf, int step, int par) {
+        const f4* src = bq + (buf * LS_ROT + step) * 256;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) bf[par][m][cb] = src[cb * 128 + rd_off[m]];
+    };
+    // ---- rows: rows past the end repeat the last row; tiles past the range repeat the last tile: loaded, never used
     auto row_ptr = [&](long long t, int rg, int hh) {
         t = t < T ? t : T - 1;
         long long row = r_lo + t * LS_TILE + rg * 16 + hh * 8 + lrow;
         row = row < r_hi ? row : r_hi - 1;
         return X4 + row * ld4 + lchunk;
     };
-    LsStep<NCB> ring[DEPTH];
+    LsStep ring[DEPTH];
     long long lt = 0;
     int ls = 0;
     const f4* lp[2][2];
@@ -116,20 +144,13 @@ __device__ __forceinline__ void ls_scan_rows(const ListScanArgs& a, f4* tp, floa
     for (int rg = 0; rg < 2; ++rg)
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) lp[rg][hh] = row_ptr(0, rg, hh);
-    auto issue = [&](LsStep<NCB>& s) {
+    auto issue = [&](LsStep& s) {
 #pragma unroll
         for (int rg = 0; rg < 2; ++rg)
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 if (RAG_LISTS_DIAG & 256) s.a[rg][hh] = (f4){(float)ls, 1.f, 2.f, 3.f};
                 else s.a[rg][hh] = __builtin_nontemporal_load(lp[rg][hh] + ls * 8);
-            }
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) {
-                if (RAG_LISTS_DIAG & 128) s.b[m][cb] = (f4){(float)ls, 1.f, 2.f, 3.f};
-                else s.b[m][cb] = qp[cb][(RAG_LISTS_DIAG & 2) ? m * 4 : (2 * ls + m) * 4];
             }
         if (++ls == steps) {
             ls = 0;
@@ -140,12 +161,13 @@ __device__ __forceinline__ void ls_scan_rows(const ListScanArgs& a, f4* tp, floa
                 for (int hh = 0; hh < 2; ++hh) lp[rg][hh] = row_ptr(lt, rg, hh);
         }
     };
+    fetch_b();                                          // the first rotation's image of this wave: the oldest load
 #pragma unroll
     for (int s = 0; s < DEPTH; ++s) issue(ring[s]);
     // The other lists' progress on this lane's queries, read ONCE per work item, behind the ring's first loads and
-    // in front of the first step: a value loaded inside the tile loop would be waited for with every younger load
-    // of the ring (loads return in order), i.e. it would drain the ring once per tile.  The wave's own thresholds
-    // tighten inside the work item; the shared word is raised again when the work item's lists are merged.
+    // in front of the first step: a value loaded inside the loop would be waited for with every younger load of the
+    // ring (loads return in order), i.e. it would drain the ring.  The wave's own thresholds tighten inside the
+    // work item; the shared word is raised again when the work item's lists are merged.
     float tg[NCB];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
@@ -153,14 +175,7 @@ __device__ __forceinline__ void ls_scan_rows(const ListScanArgs& a, f4* tp, floa
         tg[cb] = bits != 0u ? ordered_f32(bits) : -INFINITY;
     }
     f4 af[2][2][2];                                     // [parity][row group][m]
-    auto transpose = [&](const LsStep<NCB>& c, int par) {
-        if (RAG_LISTS_DIAG & 64) {
-#pragma unroll
-            for (int rg = 0; rg < 2; ++rg)
-#pragma unroll
-                for (int m = 0; m < 2; ++m) af[par][rg][m] = c.a[rg][m];
-            return;
-        }
+    auto transpose = [&](const LsStep& c, int par) {
 #pragma unroll
         for (int rg = 0; rg < 2; ++rg)
 #pragma unroll
@@ -170,7 +185,10 @@ __device__ __forceinline__ void ls_scan_rows(const ListScanArgs& a, f4* tp, floa
 #pragma unroll
             for (int m = 0; m < 2; ++m) af[par][rg][m] = tp[rg * 128 + rd_off[m]];
     };
+    write_b(0);
+    lds_barrier();
     transpose(ring[0], 0);
+    read_b(0, 0, 0);
 
     // sort every buffer holding more than min_count keys, keep its k best, tighten the threshold
     auto compact = [&](int min_count) {
@@ -202,7 +220,7 @@ __device__ __forceinline__ void ls_scan_rows(const ListScanArgs& a, f4* tp, floa
 
     // tile epilogue: lane (c = r16, kq) holds rows 4 kq .. 4 kq + 3 of each row group for column cb * 16 + c
     auto epilogue = [&](long long t, const f4 (&acc)[2][NCB]) {
-        if (RAG_LISTS_LOCKSTEP && !live) return;
+        if (!live) return;
         if (RAG_LISTS_DIAG & 1) {
             float keep = tg[0];
 #pragma unroll
@@ -263,34 +281,43 @@ __device__ __forceinline__ void ls_scan_rows(const ListScanArgs& a, f4* tp, floa
     for (int rg = 0; rg < 2; ++rg)
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) acc[rg][cb] = (f4){0.f, 0.f, 0.f, 0.f};
-    const long long rotations = T * (steps / DEPTH);
+    const long long turns = T * (steps / DEPTH);
     long long t = 0;
-    int g = 0;
-    for (long long it = 0; it < rotations; ++it) {
+    int g = 0, buf = 0;
+    for (long long it = 0; it < turns; ++it) {
 #pragma unroll
-        for (int u = 0; u < DEPTH; ++u) {
-            const int par = u & 1;
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int v = 0; v < 4; ++v)
-#pragma unroll
-                    for (int rg = 0; rg < 2; ++rg)
-#pragma unroll
-                        for (int cb = 0; cb < NCB; ++cb) {
-                            if (RAG_LISTS_DIAG & 32) acc[rg][cb][v] = fmaf(af[par][rg][m][v], ring[u].b[m][cb][v], acc[rg][cb][v]);
-                            else acc[rg][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[par][rg][m][v], ring[u].b[m][cb][v], acc[rg][cb], 0, 0, 0);
-                        }
+        for (int rr = 0; rr < DEPTH / LS_ROT; ++rr) {
+            fetch_b();                                   // this wave's image of the next rotation
             __builtin_amdgcn_sched_barrier(0);
-            // BEHIND the step's MFMAs: the next step (of this tile, or step 0 of the next one: the ring holds it already)
-            // goes through the transposer -- its rows have had DEPTH - 1 MFMA phases to arrive -- and the set that was
-            // just multiplied takes the step DEPTH ahead, so DEPTH - 1 steps are in flight while the MFMAs run
-            transpose(ring[(u + 1) % DEPTH], par ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
-            issue(ring[u]);
-            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < LS_ROT; ++u) {
+                const int slot = rr * LS_ROT + u, par = u & 1;
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+#pragma unroll
+                        for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                            for (int cb = 0; cb < NCB; ++cb)
+                                acc[rg][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[par][rg][m][v], bf[par][m][cb][v], acc[rg][cb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                // BEHIND the step's MFMAs: the next step (of this tile, or step 0 of the next one: the ring holds it
+                // already) goes through the transposer -- its rows have had DEPTH - 1 MFMA phases to arrive -- and the set
+                // that was just multiplied takes the step DEPTH ahead, so DEPTH - 1 steps are in flight while the MFMAs run
+                transpose(ring[(slot + 1) % DEPTH], par ^ 1);
+                if (u + 1 < LS_ROT) read_b(buf, u + 1, par ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                issue(ring[slot]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // the rotation ends: this wave's image of the next one goes to the other buffer (nobody reads that one:
+            // its last readers passed the previous barrier), and behind the barrier every wave's image is there
+            write_b(buf ^ 1);
+            lds_barrier();
+            buf ^= 1;
+            read_b(buf, 0, 0);
         }
-        if (RAG_LISTS_LOCKSTEP) __builtin_amdgcn_s_barrier();      // keeps the waves on the same query fragments (L1 / L2 reuse)
         g += DEPTH;
         if (g == steps) {
             epilogue(t, acc);
@@ -307,6 +334,7 @@ __device__ __forceinline__ void ls_scan_rows(const ListScanArgs& a, f4* tp, floa
 template <int DEPTH1, int DEPTH2>
 __global__ __launch_bounds__(LS_WAVES * 64, 2) void ivf_lists_kernel(ListScanArgs a) {
     __shared__ __attribute__((aligned(16))) f4 s_tp[LS_WAVES * 256];          // transposers, 4 KiB per wave
+    __shared__ __attribute__((aligned(16))) f4 s_bq[2 * LS_ROT * 256];        // query images: two rotations of four K steps, 4 KiB each
     __shared__ float s_thr[LS_WAVES * LS_QT];
     __shared__ int s_cnt[LS_WAVES * LS_QT];
     __shared__ int s_task;
@@ -338,13 +366,21 @@ __global__ __launch_bounds__(LS_WAVES * 64, 2) void ivf_lists_kernel(ListScanArg
             my_cnt[lane] = 0;
         }
         SyncWave()();
-        const long long t_all = (per + LS_TILE - 1) / LS_TILE;
-        if (r_lo < r_hi || RAG_LISTS_LOCKSTEP) {
-            // (lockstep builds: a wave without rows walks the list's last row, which its epilogue rejects)
+        {
+            // every wave walks the same number of tiles (they meet at a barrier per rotation of the query images); a
+            // wave without rows walks the list's last row and selects nothing
+            const long long t_all = (per + LS_TILE - 1) / LS_TILE;
             const bool live = r_lo < r_hi;
             const long long lo = live ? r_lo : row_hi - 1, hi = live ? r_hi : row_hi;
-            if (m_valid <= 16 && !(RAG_LISTS_DIAG & 8)) ls_scan_rows<1, DEPTH1>(a, s_tp + wave * 256, my_thr, my_cnt, my_cand, a.pair_q + p0, m_valid, lo, hi, t_all, live, lane);
-            else ls_scan_rows<2, DEPTH2>(a, s_tp + wave * 256, my_thr, my_cnt, my_cand, a.pair_q + p0, m_valid, lo, hi, t_all, live, lane);
+            f4* tp = s_tp + wave * 256;
+            const int* pq = a.pair_q + p0;
+            const bool deep = (a.ld % (32 * DEPTH1)) == 0;       // K steps per row fill whole turns of the deeper ring
+            if (m_valid <= 16 && !(RAG_LISTS_DIAG & 8)) {
+                if (deep) ls_scan_rows<1, DEPTH1>(a, tp, s_bq, my_thr, my_cnt, my_cand, pq, m_valid, lo, hi, t_all, live, wave, lane);
+                else ls_scan_rows<1, LS_ROT>(a, tp, s_bq, my_thr, my_cnt, my_cand, pq, m_valid, lo, hi, t_all, live, wave, lane);
+            } else {
+                ls_scan_rows<2, DEPTH2>(a, tp, s_bq, my_thr, my_cnt, my_cand, pq, m_valid, lo, hi, t_all, live, wave, lane);
+            }
         }
         // ---- the four waves' lists of every pair -> the pair's k keys ----------------------------------
         __syncthreads();                                 // (drains every wave's stores to its candidate buffers)
