@@ -23,7 +23,9 @@
 // score any other list of its query has reached.  A buffer past 32 keys is sorted in registers (one key per lane),
 // cut to k and the threshold tightened.  When a work item's rows are done the four waves' lists of a pair are
 // merged (two barriers per work item) and the pair's k keys go to its slot; merge_keys_*_kernel reduces a query's
-// nprobe slots as before.  Keys carry the insertion position (row_alias), masks are read where a row is tested.
+// nprobe slots as before.  Candidate keys carry the storage position (inside a list the same order as the insertion
+// position); the kept keys of a pair are renamed to insertion positions (row_alias) when they are written; masks are
+// read where a row is tested.
 //
 // Scores are a k-ordered fp32 fma chain per (row, query), independent of the launch geometry and of which
 // workgroup takes which work item.
@@ -66,6 +68,8 @@ struct LsStep {
     f4 a[2][2];
 };
 
+__device__ __forceinline__ long long row_lo_key(u64 key) { return (long long)key_row(key); }
+
 // workgroup barrier that orders LDS accesses only: the register ring's loads stay in flight across it
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -73,7 +77,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // of its workgroup: every wave walks T tiles (a wave with fewer rows re-reads its last ones and selects nothing).
 // tp: the wave's transposer; bq: the workgroup's query images [2][LS_ROT][256 f4]; my_thr / my_cnt / my_cand: the
 // wave's thresholds, counts and candidate buffers for the item's (up to 32) pairs.
-template <int NCB, int DEPTH>
+template <int NCB, int DEPTH, bool MASKED>
 __device__ __forceinline__ void ls_scan_rows(const ListScanArgs& a, f4* tp, f4* bq, float* my_thr, int* my_cnt, u64* my_cand,
                                              const int* pq, int m_valid, long long r_lo, long long r_hi, long long T, bool live,
                                              int wave, int lane) {
@@ -218,6 +222,7 @@ __device__ __forceinline__ void ls_scan_rows(const ListScanArgs& a, f4* tp, f4* 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
 
+    constexpr bool has_mask = MASKED;          // a kernel of its own: the unmasked epilogue must not contain a load at all
     // tile epilogue: lane (c = r16, kq) holds rows 4 kq .. 4 kq + 3 of each row group for column cb * 16 + c
     auto epilogue = [&](long long t, const f4 (&acc)[2][NCB]) {
         if (!live) return;
@@ -255,10 +260,18 @@ __device__ __forceinline__ void ls_scan_rows(const ListScanArgs& a, f4* tp, f4* 
                     const float sc = acc[rg][cb][reg];
                     const long long row = row_base + rg * 16 + reg;
                     if (sc > thr[cb] && sc >= tg[cb] && row < r_hi) {
-                        const long long shown = a.row_alias ? a.row_alias[row] : row;     // the position keys and masks use
-                        if ((!a.mask || a.mask[shown]) && (!a.mask2 || a.mask2[shown])) {
+                        // Candidate keys carry the STORAGE position: inside a list storage order is insertion order, so ties
+                        // fall the same way, and the position a caller sees is looked up once per kept key when the work
+                        // item's lists are merged.  Without masks a push therefore loads nothing (a load here would be
+                        // waited for together with every load of the ring).
+                        bool ok = true;
+                        if constexpr (has_mask) {
+                            const long long shown = a.row_alias ? a.row_alias[row] : row;     // masks count rows in insertion order
+                            ok = (!a.mask || a.mask[shown]) && (!a.mask2 || a.mask2[shown]);
+                        }
+                        if (ok) {
                             const int pos = atomicAdd(&my_cnt[q], 1);
-                            my_cand[(size_t)q * LS_CAP + pos] = make_key(sc, (uint32_t)shown);
+                            my_cand[(size_t)q * LS_CAP + pos] = make_key(sc, (uint32_t)row);
                             over |= pos + 1 > LS_TRIG;
                         }
                     }
@@ -268,10 +281,12 @@ __device__ __forceinline__ void ls_scan_rows(const ListScanArgs& a, f4* tp, f4* 
         if (__ballot(over) != 0ull) {
             SyncWave()();                                // the lanes' LDS updates, in order, before the counts are read
             compact(LS_TRIG);
+            // this (rare) path ends with nothing outstanding: where it joins the common path the compiler otherwise
+            // waits for every load of the ring (it merges the two paths' outstanding-load state conservatively)
+            __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
+        } else if constexpr (has_mask) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);
         }
-        // this (rare) path ends with nothing outstanding: where it joins the common path the compiler otherwise waits
-        // for every load of the ring (it merges the two paths' outstanding-load state conservatively)
-        __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)
     };
 
     // ONE loop over every ring rotation of every tile (the epilogue sits inside it behind a wave-uniform branch): a
@@ -331,7 +346,7 @@ __device__ __forceinline__ void ls_scan_rows(const ListScanArgs& a, f4* tp, f4* 
     }
 }
 
-template <int DEPTH1, int DEPTH2>
+template <int DEPTH1, int DEPTH2, bool MASKED>
 __global__ __launch_bounds__(LS_WAVES * 64, 2) void ivf_lists_kernel(ListScanArgs a) {
     __shared__ __attribute__((aligned(16))) f4 s_tp[LS_WAVES * 256];          // transposers, 4 KiB per wave
     __shared__ __attribute__((aligned(16))) f4 s_bq[2 * LS_ROT * 256];        // query images: two rotations of four K steps, 4 KiB each
@@ -376,10 +391,10 @@ __global__ __launch_bounds__(LS_WAVES * 64, 2) void ivf_lists_kernel(ListScanArg
             const int* pq = a.pair_q + p0;
             const bool deep = (a.ld % (32 * DEPTH1)) == 0;       // K steps per row fill whole turns of the deeper ring
             if (m_valid <= 16 && !(RAG_LISTS_DIAG & 8)) {
-                if (deep) ls_scan_rows<1, DEPTH1>(a, tp, s_bq, my_thr, my_cnt, my_cand, pq, m_valid, lo, hi, t_all, live, wave, lane);
-                else ls_scan_rows<1, LS_ROT>(a, tp, s_bq, my_thr, my_cnt, my_cand, pq, m_valid, lo, hi, t_all, live, wave, lane);
+                if (deep) ls_scan_rows<1, DEPTH1, MASKED>(a, tp, s_bq, my_thr, my_cnt, my_cand, pq, m_valid, lo, hi, t_all, live, wave, lane);
+                else ls_scan_rows<1, LS_ROT, MASKED>(a, tp, s_bq, my_thr, my_cnt, my_cand, pq, m_valid, lo, hi, t_all, live, wave, lane);
             } else {
-                ls_scan_rows<2, DEPTH2>(a, tp, s_bq, my_thr, my_cnt, my_cand, pq, m_valid, lo, hi, t_all, live, wave, lane);
+                ls_scan_rows<2, DEPTH2, MASKED>(a, tp, s_bq, my_thr, my_cnt, my_cand, pq, m_valid, lo, hi, t_all, live, wave, lane);
             }
         }
         // ---- the four waves' lists of every pair -> the pair's k keys ----------------------------------
@@ -415,6 +430,8 @@ __global__ __launch_bounds__(LS_WAVES * 64, 2) void ivf_lists_kernel(ListScanArg
                     best = wave_sort_desc(both, lane);
                 }
             }
+            // storage position -> the position callers see (equal scores keep their order: within a list both orders agree)
+            if (a.row_alias && best != KEY_EMPTY) best = (best & 0xFFFFFFFF00000000ull) | (u64)(0xFFFFFFFFu - (uint32_t)a.row_alias[row_lo_key(best)]);
             if (lane < k) a.part[(size_t)a.pair_slot[p0 + q] * k + lane] = best;
             const u64 kth = readlane_u64(best, k - 1);
             if (kth != KEY_EMPTY && lane == 0) atomicMax(&a.gthr[a.pair_q[p0 + q]], f32_ordered(key_score(kth)));
@@ -438,7 +455,9 @@ size_t ivf_lists_cand_bytes() { return (size_t)LS_GRID * LS_WAVES * LS_QT * LS_C
 
 int ivf_lists_launch(const ListScanArgs& a, hipStream_t s) {
     static const int grid = std::max(1, env_int_l("RAG_IVF_LISTS_GRID", LS_GRID));      // measurement knob (<= LS_GRID: the candidate buffers)
-    hipLaunchKernelGGL((ivf_lists_kernel<RAG_LISTS_DEPTH1, RAG_LISTS_DEPTH2>), dim3(std::min(grid, LS_GRID)), dim3(LS_WAVES * 64), 0, s, a);
+    const dim3 g(std::min(grid, LS_GRID)), b(LS_WAVES * 64);
+    if (a.mask || a.mask2) hipLaunchKernelGGL((ivf_lists_kernel<RAG_LISTS_DEPTH1, RAG_LISTS_DEPTH2, true>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((ivf_lists_kernel<RAG_LISTS_DEPTH1, RAG_LISTS_DEPTH2, false>), g, b, 0, s, a);
     RAG_HIP_CHECK(hipGetLastError());
     return RAG_OK;
 }
