@@ -679,6 +679,10 @@ static int search_device_ordered(rag_index* h, int64_t nq, const float* q_dev, i
 }  // extern "C"
 
 namespace rag {
+void launch_fill_results(float* D, long long* I, long long n, hipStream_t s) {
+    hipLaunchKernelGGL(fill_results_kernel, dim3(grid_for(n)), dim3(256), 0, s, D, I, n);
+}
+
 // Forget the rows at and behind position n -- the way a caller that spreads one add over several indexes takes back
 // the parts that went through when another part failed.  Only rows that no search has seen: an IVF index must not
 // have packed them into its lists yet (they still wait at the tail in arrival order).

@@ -100,6 +100,11 @@ struct SelectArgs {
     int segs;                    // 1: one segment per query
     long long n_row;             // scores per query row (n when segs == 1)
     long long out_stride;        // hits between the lists of consecutive segments (0 when segs == 1)
+    // nullptr, or per query a score no answer can lie below (floor[q * floor_stride]: the k-th best score of rows that
+    // come EARLIER in the order rule, -FLT_MAX when there are fewer than k): scores under it are left out before anything
+    // is binned, and when what is left fits the candidate array it is ranked directly
+    const float* floor;
+    long long floor_stride;
 };
 
 template <int SEL_REG>                  // scores per thread: n <= SEL_REG * 1024
@@ -118,15 +123,17 @@ __global__ __launch_bounds__(1024) void direct_select_kernel(SelectArgs p) {
     __shared__ int hist[1024];
     __shared__ u64 cand[SEL_CAP];
     __shared__ u64 s_lo, s_hi, s_bound;
-    __shared__ int s_cnt, s_above, s_done;
+    __shared__ int s_cnt, s_above, s_done, s_valid;
     const int tid = threadIdx.x, lane = tid & 63;
     const float* sc = p.scores + (size_t)qi * p.n_row + seg_lo;
-    if (tid == 0) { s_lo = ~0ull; s_hi = 0ull; }
+    if (tid == 0) { s_lo = ~0ull; s_hi = 0ull; s_valid = 0; }
     __syncthreads();
     u64 head = KEY_EMPTY;                                          // this thread's best key
     // the thread's scores (rows tid, tid + 1024, ...) stay in registers for every later pass; a masked row
     // or one past the end is a NaN, which never becomes a key
     float v[SEL_REG];
+    const float floor_sc = p.floor ? p.floor[(size_t)qi * p.floor_stride] : -INFINITY;
+    int nvalid_w = 0;                                              // keys of this wave that may be in the answer
     {
         u64 mn = ~0ull, mx = 0ull;
 #pragma unroll
@@ -142,6 +149,7 @@ __global__ __launch_bounds__(1024) void direct_select_kernel(SelectArgs p) {
             }
 #pragma unroll
             for (int u = u0; u < u0 + 8; ++u) {
+                if (v[u] < floor_sc) v[u] = NAN;                   // k earlier rows score at least the floor
                 const u64 key = make_key(v[u], (uint32_t)(tid + u * 1024));
                 if (key != KEY_EMPTY) { mn = key < mn ? key : mn; mx = key > mx ? key : mx; }
             }
@@ -154,18 +162,27 @@ __global__ __launch_bounds__(1024) void direct_select_kernel(SelectArgs p) {
             mx = omx > mx ? omx : mx;
         }
         if (lane == 0 && mx != 0ull) { atomicMin(&s_lo, mn); atomicMax(&s_hi, mx); }
+        if (p.floor) {
+#pragma unroll
+            for (int u = 0; u < SEL_REG; ++u) nvalid_w += v[u] == v[u] ? 1 : 0;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) nvalid_w += __shfl_xor(nvalid_w, off, 64);
+            if (lane == 0 && nvalid_w) atomicAdd(&s_valid, nvalid_w);
+        }
     }
     const int nheads = __syncthreads_count(head != KEY_EMPTY);
     const u64 glo = s_lo, ghi = s_hi;
     int cnum = 0;
-    for (int mode = (nheads >= k ? 0 : 1); mode < 2 && ghi >= glo; ++mode) {
+    // behind a floor few keys are left: when they fit the candidate array all of them are candidates, no bound to look for
+    const bool all_fit = p.floor && s_valid <= SEL_CAP;
+    for (int mode = (nheads >= k && !all_fit ? 0 : 1); mode < 2 && ghi >= glo; ++mode) {
         const bool by_heads = mode == 0;
         __syncthreads();
-        if (tid == 0) { s_cnt = 0; s_above = 0; s_done = 0; s_bound = KEY_EMPTY; s_lo = glo; s_hi = ghi; }
+        if (tid == 0) { s_cnt = 0; s_above = 0; s_done = 0; s_bound = all_fit ? 1ull : KEY_EMPTY; s_lo = glo; s_hi = ghi; }
         __syncthreads();
         u64 lo = glo, hi = ghi;
         // every pass keeps: keys above `hi` are selected for sure (s_above of them), the k-th key lies in [lo, hi]
-        for (int pass = 0; pass < 8; ++pass) {
+        for (int pass = 0; pass < 8 && !all_fit; ++pass) {
             const int shift = (hi > lo) ? max(0, 64 - __clzll((long long)(hi - lo)) - 10) : 0;
             hist[tid] = 0;
             __syncthreads();
@@ -261,7 +278,7 @@ int direct_select_rows(long long nq, int n, int k, float min_score, const uint8_
                        long long* rows_out, const float* scores, float* D, long long* I, hipStream_t s);
 int direct_select_segments(long long nq, long long n_row, long long seg_rows, int k, float min_score, const uint8_t* mask,
                            const long long* row_ids, long long id_base, const float* scores, float* D, long long* I, long long out_stride,
-                           hipStream_t s);
+                           const float* floor, long long floor_stride, hipStream_t s);
 
 bool direct_topk_supported(const rag_index* h, long long nq, int k) {
     static const int on = getenv("RAG_DIRECT_TOPK") ? atoi(getenv("RAG_DIRECT_TOPK")) : 1;          // measurement knob
@@ -326,7 +343,7 @@ int direct_select_rows(long long nq, int n, int k, float min_score, const uint8_
 // query q starts at hit g * out_stride + q * k of D and I
 int direct_select_segments(long long nq, long long n_row, long long seg_rows, int k, float min_score, const uint8_t* mask,
                            const long long* row_ids, long long id_base, const float* scores, float* D, long long* I, long long out_stride,
-                           hipStream_t s) {
+                           const float* floor, long long floor_stride, hipStream_t s) {
     const long long seg = (long long)SEL_REG_MAX * 1024;
     const long long segs = (n_row + seg - 1) / seg;
     if (seg_rows != seg || segs < 1 || nq * segs > 0x7fffffffLL) return fail(RAG_ERR_INVALID, "internal: segment selection grid");
@@ -344,6 +361,8 @@ int direct_select_segments(long long nq, long long n_row, long long seg_rows, in
     p.segs = (int)segs;
     p.n_row = n_row;
     p.out_stride = out_stride;
+    p.floor = floor;
+    p.floor_stride = floor_stride;
     hipLaunchKernelGGL(direct_select_kernel<SEL_REG_MAX>, dim3((unsigned)(nq * segs)), dim3(1024), 0, s, p);
     RAG_HIP_CHECK(hipGetLastError());
     return RAG_OK;

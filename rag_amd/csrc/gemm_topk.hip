@@ -1217,9 +1217,10 @@ static SegPlan seg_plan(const rag_index* h, long long nq, int k) {
     const long long group_rows = std::min<long long>(h->n, p.group * SCORES_MAX_ROWS);
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     p.scores_bytes = al((size_t)p.qc * group_rows * sizeof(float));
-    p.d_bytes = al((size_t)p.nseg * p.qc * k * sizeof(float));
-    p.i_bytes = al((size_t)p.nseg * p.qc * k * sizeof(long long));
-    p.keys_bytes = al((size_t)p.nseg * p.qc * k * sizeof(u64));
+    // lists of one group of segments behind the running answer (list 0)
+    p.d_bytes = al((size_t)(p.group + 1) * p.qc * k * sizeof(float));
+    p.i_bytes = al((size_t)(p.group + 1) * p.qc * k * sizeof(long long));
+    p.keys_bytes = al((size_t)(p.group + 1) * p.qc * k * sizeof(u64));
     return p;
 }
 size_t gemm_segments_workspace(const rag_index* h, long long nq, int k) {
@@ -1229,7 +1230,8 @@ size_t gemm_segments_workspace(const rag_index* h, long long nq, int k) {
 
 int direct_select_segments(long long nq, long long n_row, long long seg_rows, int k, float min_score, const uint8_t* mask,
                            const long long* row_ids, long long id_base, const float* scores, float* D, long long* I, long long out_stride,
-                           hipStream_t s);   // direct_topk.hip
+                           const float* floor, long long floor_stride, hipStream_t s);   // direct_topk.hip
+void launch_fill_results(float* D, long long* I, long long n, hipStream_t s);                // api.hip
 
 int gemm_segments_search(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask, float* D,
                          long long* I, hipStream_t s) {
@@ -1247,15 +1249,36 @@ int gemm_segments_search(rag_index* h, long long nq, const float* qbuf, int k, f
         // the last chunk of a batch may be shorter than the chunk the group was planned for: its shape follows its own size
         const int QT = qc >= 512 ? 256 : qc > 64 ? 128 : qc > 32 ? 64 : 32;
         const int RT = QT == 32 ? 256 : QT == 64 ? 128 : QT;
+        // The running answer of the chunk is list 0 of Dseg / Iseg; a group's segments leave their lists behind it, and one
+        // merge per group folds them in (ties to the lower list = the lower row).  Its k-th score is the floor of the next
+        // group's selection: after g groups of G segments a segment holds about k / (g G) rows above it instead of k, so
+        // its selection ranks a handful of keys directly instead of searching a bound among 32768.
+        const size_t lstride = (size_t)qc * k;
+        float* Dout = D + (size_t)q0 * k;
+        long long* Iout = I + (size_t)q0 * k;
+        launch_fill_results(Dseg, Iseg, (long long)lstride, s);
+        auto fold = [&](long long sg, long long segs_here) -> int {
+            if (int rc = merge_lists_device((int)segs_here + 1, qc, k, Dseg, (long long)lstride, Iseg, (long long)lstride, Dout, Iout, keys, s)) return rc;
+            if (sg + segs_here < p.nseg) {       // the answer so far goes back to list 0
+                RAG_HIP_CHECK(hipMemcpyAsync(Dseg, Dout, lstride * sizeof(float), hipMemcpyDeviceToDevice, s));
+                RAG_HIP_CHECK(hipMemcpyAsync(Iseg, Iout, lstride * sizeof(long long), hipMemcpyDeviceToDevice, s));
+            }
+            return RAG_OK;
+        };
+        static const int use_floor = env_int_g("RAG_GEMM_SEGMENTS_FLOOR", 1);        // measurement knob
         for (long long sg = 0; sg < p.nseg; sg += p.group) {
             const long long lo = sg * SCORES_MAX_ROWS, rows = std::min<long long>(p.group * SCORES_MAX_ROWS, h->n - lo);
+            const long long segs_here = (rows + SCORES_MAX_ROWS - 1) / SCORES_MAX_ROWS;
+            // (a floor only where min_score cannot empty list 0: the floor is the k-th kept score, kept means >= min_score)
+            const float* floor = (use_floor && sg > 0) ? Dseg + (k - 1) : nullptr;
             if (narrow_scores_supported(h, qc)) {
                 // up to 32 queries: the register-streaming kernel reads the rows at the HBM rate (narrow_topk.hip)
                 if (int rc = narrow_scores_launch(h, h->X + (size_t)lo * h->ld, rows, qc, qbuf + (size_t)q0 * h->ld, scores, s)) return rc;
                 if (int rc2 = direct_select_segments(qc, rows, SCORES_MAX_ROWS, k, min_score, mask ? mask + lo : nullptr,
                                                      h->ids_dev ? h->ids_dev + lo : nullptr, h->id_base + lo, scores,
-                                                     Dseg + (size_t)sg * qc * k, Iseg + (size_t)sg * qc * k, qc * k, s))
+                                                     Dseg + lstride, Iseg + lstride, (long long)lstride, floor, k, s))
                     return rc2;
+                if (int rc3 = fold(sg, segs_here)) return rc3;
                 continue;
             }
             GemmArgs a = {};
@@ -1282,10 +1305,11 @@ int gemm_segments_search(rag_index* h, long long nq, const float* qbuf, int k, f
             else rc = launch_gemm_store<256, 32, 4>(a, grid, h->device, s);
             if (rc) return rc;
             if (int rc2 = direct_select_segments(qc, rows, SCORES_MAX_ROWS, k, min_score, mask ? mask + lo : nullptr,
-                                                 h->ids_dev ? h->ids_dev + lo : nullptr, h->id_base + lo, scores, Dseg + (size_t)sg * qc * k, Iseg + (size_t)sg * qc * k, qc * k, s))
+                                                 h->ids_dev ? h->ids_dev + lo : nullptr, h->id_base + lo, scores, Dseg + lstride, Iseg + lstride,
+                                                 (long long)lstride, floor, k, s))
                 return rc2;
+            if (int rc3 = fold(sg, segs_here)) return rc3;
         }
-        if (int rc = merge_lists_device((int)p.nseg, qc, k, Dseg, qc * k, Iseg, qc * k, D + (size_t)q0 * k, I + (size_t)q0 * k, keys, s)) return rc;
     }
     if (int rc = profile_end(h, s)) return rc;
     h->last_path = "gemm-segments";

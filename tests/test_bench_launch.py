@@ -40,6 +40,17 @@ def test_gpus_2_without_a_launcher_spawns_two_ranks():
     assert out["value"] > 0 and abs(out["ms_per_step"] * out["value"] - 1e3) < 1e-6 * 1e3
 
 
+def test_gpus_8_without_a_launcher_spawns_eight_ranks():
+    """The rank count of the 8-GPU configurations: eight shards, one all-gather per step, every rank ends with the
+    whole corpus's answer."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--steps", "3", "--warmup", "1", "--stub-cpu"],
+                       env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _json_line(r.stdout)
+    assert out["n_gpus"] == 8 and out["world_size"] == 8 and out["exchange_ok"] is True
+    assert out["config"]["rows_per_gpu"] * 8 >= out["config"]["rows"]
+
+
 def test_under_a_launcher_the_same_line_comes_out():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

@@ -102,8 +102,9 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_device_path_with_several_ranks_on_one_gpu(tmp_path, world):
+    """world 8 = the rank count of the 8-GPU configurations: slot layout, shard ranges and the merge of eight lists."""
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
@@ -128,3 +129,21 @@ def test_bench_with_two_ranks_on_one_gpu():
     assert out["scaling"] == "strong" and out["value"] > 0
     assert out["roofline"]["launches"] == 5
     assert "batch_1024" in out
+    assert out["verified"] and all(out["verified"].values()), out["verified"]
+
+
+def test_bench_with_eight_ranks_on_one_gpu():
+    """The launch the driver uses for the 8-GPU scaling point (`python bench.py --gpus 8`), rehearsed with the eight
+    ranks sharing the one GPU over gloo: eight row shards of 100 000 rows, one all-gather per step, the device merge
+    of eight lists on every rank, and every rank's answers verified."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "5", "--warmup", "2",
+                        "--rows", "800000", "--big-batch", "512", "--big-steps", "2", "--no-cpu", "--no-side", "--no-prefilter",
+                        "--dist-backend", "gloo", "--share-gpu"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["world_size"] == 8
+    assert out["config"]["rows_per_gpu"] == 100000 and out["config"]["dist_backend"] == "gloo"
+    assert out["verified"] and all(out["verified"].values()), out["verified"]
