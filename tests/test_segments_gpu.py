@@ -308,12 +308,18 @@ def test_a_payload_with_an_empty_chunk_id_keeps_the_host_fusion():
         content[:6] = Q[0] + 0.01 * rng.standard_normal((6, d)).astype(np.float32)      # the best hits of query 0 ...
         ids = [f"doc_{doc}_chunk_{i}" for i in range(n)]
         meta = [{"document_id": doc, "text": f"{doc}/{i}", "user_id": 7} for i in range(n)]
-        if doc == 2:
-            meta[0]["chunk_id"] = ""                                                     # ... one of which has no chunk id
-            meta[3]["chunk_id"] = None
         for m in (plain, pooled):
             assert run(m.create_index(f"doc_{doc}", d))
-            assert run(m.add_vectors(f"doc_{doc}", content.tolist(), content.tolist(), meta, ids)) == ids
+            if doc == 1:
+                assert run(m.add_vectors(f"doc_{doc}", content.tolist(), content.tolist(), meta, ids)) == ids
+                continue
+            # document 2's points come in below the manager (a collection filled by another writer, registered with
+            # add_collection in the reference): add_vectors itself always stamps a chunk id into the payload
+            payloads = [dict(p, chunk_id=cid, index_name="doc_2") for p, cid in zip(meta, ids)]
+            payloads[0]["chunk_id"] = ""                                                 # ... one of which has no chunk id
+            payloads[3]["chunk_id"] = None
+            for vtype in ("content", "context"):
+                m.search_optimizers[f"doc_2_{vtype}"].upsert(content, payloads, ids)
     strat = [("full_query", Q[0].tolist(), 0.4), ("concepts", Q[1].tolist(), 0.6), ("expanded", Q[2].tolist(), 0.3)]
     pool = pooled.search_optimizers["doc_1_content"].pool
     assert pool.chunk_ids_distinct("doc_1_content") and not pool.chunk_ids_distinct("doc_2_content")
