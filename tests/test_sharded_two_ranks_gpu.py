@@ -72,8 +72,14 @@ def _worker(rank, world, port, out_dir):
                                                             "fuse_limit": 80, "max_results": 25}):
         a = sh.hybrid_mmr(q, 200, bm_rows, bm_scores, want_fused=True, **kw)
         b = hybrid_mmr(whole, q, 200, bm_rows, bm_scores, want_fused=True, **kw)
-        for name in ("ids", "scores", "picked", "fused_rows", "fused_scores", "fused_sem", "fused_bm"):
-            if not np.array_equal(np.asarray(a[name]), np.asarray(b[name])):
+        # ids and orderings equal; scores bit for bit where a shard is scored by the kernel the whole index uses (shards
+        # above 32768 rows, like the whole index: the scan), else within the tolerance of the exhaustive search -- a
+        # shard's row count selects its kernel, i.e. its summation order
+        same_kernel = (hi - lo) > 32768
+        for name in ("ids", "picked", "fused_rows", "scores", "fused_scores", "fused_sem", "fused_bm"):
+            x, y = np.asarray(a[name]), np.asarray(b[name])
+            exact = same_kernel or name in ("ids", "picked", "fused_rows", "fused_bm")
+            if x.shape != y.shape or not (np.array_equal(x, y) if exact else np.allclose(x, y, rtol=1e-5, atol=1e-6)):
                 problems.append(("hybrid_mmr", name, repr(kw)))
         if a["status"] != b["status"] or a["n_fused"] != b["n_fused"] or len(a["ids"]) == 0:
             problems.append(("hybrid_mmr", "status / counts", repr(kw)))
