@@ -574,8 +574,8 @@ def leg_ivf_share(torch, args, device, rows=12_500_000, dim=1024, nlist=16384, n
     (lists of average length)."""
     from rag_amd import DeviceIndex
     free, _ = torch.cuda.mem_get_info(device)
-    if free < 2.3 * rows * dim * 4:
-        return {"skipped": f"needs {2.3 * rows * dim * 4 / 2**30:.0f} GiB of free HBM, {free / 2**30:.0f} free"}
+    if free < 1.2 * rows * dim * 4:          # the rows once (they are packed into their lists in place) + workspaces
+        return {"skipped": f"needs {1.2 * rows * dim * 4 / 2**30:.0f} GiB of free HBM, {free / 2**30:.0f} free"}
     g = torch.Generator(device=device)
     g.manual_seed(99)
     C = torch.nn.functional.normalize(torch.randn(nlist, dim, device=device, generator=g), dim=1)
@@ -643,7 +643,7 @@ def leg_ivf_share(torch, args, device, rows=12_500_000, dim=1024, nlist=16384, n
             per_list = nq * nprobe / nlist
             read_once = rows * dim * 4 * (1.0 - math.exp(-per_list))        # lists probed at all (Poisson), each read once
             gbs = read_once / (scan_ms * 1e-3) / 1e9 if launches else 0.0
-            leg["roofline"] = {"bound": "hbm", "kernel": "gemm_topk_kernel<256,32,4,TASKS>", "achieved": gbs,
+            leg["roofline"] = {"bound": "hbm", "kernel": "ivf_lists_kernel", "achieved": gbs,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                                "kernel_ms": scan_ms, "launches": launches, "algorithmic_bytes_per_launch": read_once,
                                "note": "every probed list read once (lists probed by more than 32 queries are read again)",
@@ -925,7 +925,7 @@ def main(argv=None):
         if cpu is not None:
             out["cpu_baseline"] = cpu
         if world == 1 and not args.no_side:
-            # the corpus of the headline legs is released first: the IVF share alone needs 2 x 51 GB while it packs
+            # the corpus of the headline legs is released first: the IVF share is 51 GB of rows
             index.close()
             del X, index
             torch.cuda.empty_cache()

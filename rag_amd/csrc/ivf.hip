@@ -129,7 +129,25 @@ int ivf_assign_new_rows(rag_index* h, long long first, long long count) {
     return RAG_OK;
 }
 
-// fold the unsorted tail into list order
+// rows from[i] -> rows to[i] of the same buffer (the two sets do not overlap); one wave per row
+__global__ void move_rows_kernel(float* X, const long long* from, const long long* to, long long m, int ld4) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
+    const long long nw = ((long long)gridDim.x * blockDim.x) >> 6;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4* x4 = reinterpret_cast<f4*>(X);
+    for (long long i = wave; i < m; i += nw) {
+        const long long s = from[i], d = to[i];
+        for (int c = lane; c < ld4; c += 64) x4[d * ld4 + c] = x4[s * ld4 + c];
+    }
+}
+
+// Fold the unsorted tail into list order, IN PLACE: the rows are permuted inside their buffer one destination chunk at a
+// time through a staging block of at most ~1 GB, so packing 51 GB of rows needs 52 GB, not 102.  Per chunk [c0, c1) of
+// the final order: (1) the rows that belong there are gathered into the staging block (they sit in the chunk itself or
+// behind it -- everything in front is final); (2) the rows that sit in the chunk but belong behind it move into the
+// places step 1 vacated behind the chunk (as many as it vacated); (3) the staging block is copied over the chunk.
+// The host keeps who-is-where up to date; every row moves at most three times.
 static int ivf_repack(rag_index* h) {
     IvfState& v = h->ivf;
     const long long n = h->n;
@@ -143,28 +161,65 @@ static int ivf_repack(rag_index* h) {
     for (long long o = 0; o < n; ++o) begin[(size_t)v.assign[(size_t)o] + 1]++;
     for (int l = 0; l < v.nlist; ++l) begin[(size_t)l + 1] += begin[(size_t)l];
     std::vector<long long> cursor(begin.begin(), begin.end() - 1);
-    std::vector<long long> new_orig((size_t)n), src((size_t)n);
+    std::vector<long long> new_orig((size_t)n), new_pos((size_t)n);
     for (long long o = 0; o < n; ++o) {
         const long long p = cursor[(size_t)v.assign[(size_t)o]]++;
         new_orig[(size_t)p] = o;
-        src[(size_t)p] = v.pos[(size_t)o];
+        new_pos[(size_t)o] = p;
     }
-    // device: gather rows into a fresh buffer in the new order
-    float* nx = nullptr;
-    RAG_HIP_CHECK(hipMalloc((void**)&nx, (size_t)std::max(h->cap, n) * h->ld * sizeof(float)));
-    if (int rc = v.ws.ensure((size_t)n * sizeof(long long))) { (void)hipFree(nx); return rc; }
-    RAG_HIP_CHECK(hipMemcpyAsync(v.ws.ptr, src.data(), (size_t)n * sizeof(long long), hipMemcpyHostToDevice, h->stream));
-    long long blocks = (n + 3) / 4;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(gather_packed_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, h->X,
-                       static_cast<const long long*>(v.ws.ptr), n, h->ld / 4, nx);
-    RAG_HIP_CHECK(hipGetLastError());
-    RAG_HIP_CHECK(hipStreamSynchronize(h->stream));
-    (void)hipFree(h->X);
-    h->X = nx;
-    h->cap = std::max(h->cap, n);
-    v.orig.swap(new_orig);
-    for (long long p = 0; p < n; ++p) v.pos[(size_t)v.orig[(size_t)p]] = p;
+    static const long long chunk_bytes = std::max(1, getenv("RAG_IVF_PACK_CHUNK_MB") ? atoi(getenv("RAG_IVF_PACK_CHUNK_MB")) : 1024) * (1LL << 20);
+    const long long B = std::max<long long>(1, std::min<long long>(n, chunk_bytes / ((long long)h->ld * 4)));
+    const size_t row_bytes = (size_t)h->ld * sizeof(float);
+    const size_t idx_bytes = (((size_t)B * sizeof(long long)) + 255) & ~(size_t)255;
+    if (int rc = v.ws.ensure((size_t)B * row_bytes + 3 * idx_bytes)) return rc;
+    float* stage = static_cast<float*>(v.ws.ptr);
+    long long* d_src = reinterpret_cast<long long*>(static_cast<char*>(v.ws.ptr) + (size_t)B * row_bytes);
+    long long* d_from = reinterpret_cast<long long*>(reinterpret_cast<char*>(d_src) + idx_bytes);
+    long long* d_to = reinterpret_cast<long long*>(reinterpret_cast<char*>(d_from) + idx_bytes);
+    std::vector<long long> src, from, to;
+    for (long long c0 = 0; c0 < n; c0 += B) {
+        const long long c1 = std::min(n, c0 + B), cnt = c1 - c0;
+        src.resize((size_t)cnt);
+        from.clear();
+        to.clear();
+        bool identity = true;
+        for (long long p = c0; p < c1; ++p) {
+            const long long s = v.pos[(size_t)new_orig[(size_t)p]];        // where the row that belongs at p sits now
+            src[(size_t)(p - c0)] = s;
+            identity = identity && s == p;
+            if (s >= c1) to.push_back(s);                                  // a place behind the chunk falls vacant
+        }
+        if (identity) continue;                                            // the chunk is in order already (re-packs: the packed head)
+        for (long long q = c0; q < c1; ++q)
+            if (new_pos[(size_t)v.orig[(size_t)q]] >= c1) from.push_back(q);   // sits in the chunk, belongs behind it
+        if (from.size() != to.size()) return fail(RAG_ERR_HIP, "internal: the in-place pack lost count of its rows");
+        RAG_HIP_CHECK(hipMemcpyAsync(d_src, src.data(), (size_t)cnt * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+        long long blocks = std::min<long long>((cnt + 3) / 4, 8192);
+        hipLaunchKernelGGL(gather_packed_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, h->X, d_src, cnt, h->ld / 4, stage);
+        RAG_HIP_CHECK(hipGetLastError());
+        const long long m = (long long)from.size();
+        if (m > 0) {
+            RAG_HIP_CHECK(hipMemcpyAsync(d_from, from.data(), (size_t)m * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+            RAG_HIP_CHECK(hipMemcpyAsync(d_to, to.data(), (size_t)m * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+            blocks = std::min<long long>((m + 3) / 4, 8192);
+            hipLaunchKernelGGL(move_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, h->X, d_from, d_to, m, h->ld / 4);
+            RAG_HIP_CHECK(hipGetLastError());
+        }
+        RAG_HIP_CHECK(hipMemcpyAsync(h->X + (size_t)c0 * h->ld, stage, (size_t)cnt * row_bytes, hipMemcpyDeviceToDevice, h->stream));
+        // the index arrays above are reused by the next chunk: its uploads wait for this chunk's kernels here
+        RAG_HIP_CHECK(hipStreamSynchronize(h->stream));
+        // bookkeeping: the moved rows first, then the chunk's final occupants
+        for (long long j = 0; j < m; ++j) {
+            const long long o = v.orig[(size_t)from[(size_t)j]];
+            v.orig[(size_t)to[(size_t)j]] = o;
+            v.pos[(size_t)o] = to[(size_t)j];
+        }
+        for (long long p = c0; p < c1; ++p) {
+            const long long o = new_orig[(size_t)p];
+            v.orig[(size_t)p] = o;
+            v.pos[(size_t)o] = p;
+        }
+    }
     if (v.orig_cap < n) {
         if (v.orig_dev) (void)hipFree(v.orig_dev);
         v.orig_cap = std::max(n, v.orig_cap + v.orig_cap / 2);

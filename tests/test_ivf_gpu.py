@@ -277,3 +277,45 @@ def test_ivf_soft_deletes_and_filter_mask_together():
     D, I = idx.search(Q, 1, nprobe=nprobe)
     assert np.array_equal(I[:, 0], dead[:5])
     idx.close()
+
+
+_PACK_SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from oracle import flat, ivf
+from rag_amd import DeviceIndex
+rng = np.random.default_rng(12)
+n, d, nlist, nprobe, k = 60_000, 128, 48, 6, 10
+X = rng.standard_normal((n, d)).astype(np.float32)
+X /= np.linalg.norm(X, axis=1, keepdims=True)
+C = X[rng.choice(n, nlist, replace=False)].copy()
+Q = X[rng.choice(n, 40, replace=False)] + 0.05 * rng.standard_normal((40, d)).astype(np.float32)
+iv = DeviceIndex(d, metric="ip", kind="ivf")
+iv.train_ivf(nlist, centroids=C)
+done = 0
+for part in (25_000, 20_000, 14_000, 1_000):          # every search packs the rows that arrived since the last one
+    iv.add(X[done:done + part])
+    done += part
+    for nq in (1, 40):
+        D, I = iv.search(Q[:nq], k, nprobe=nprobe)
+        bad, excused, amb = ivf.ivf_check(D, I, X[:done], C, Q[:nq], k, nprobe, rtol=1e-5, atol=1e-6)
+        assert bad == [], (done, nq, bad[:3])
+    rows = rng.integers(0, done, 500)
+    assert np.array_equal(iv.reconstruct(rows), X[rows]), done
+assert np.array_equal(iv.reconstruct(np.arange(n)), X)
+print("PACK_OK")
+"""
+
+
+def test_in_place_pack_in_many_chunks():
+    """The in-place pack with a 1 MB staging block (2048 rows of 128 floats): 30 destination chunks per pack, rows moving
+    between chunks, four packs in a row (the packed head of a re-pack is in order already).  Answers against the oracle,
+    every stored row read back unchanged.  (Its own process: the chunk size is read once per process.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RAG_IVF_PACK_CHUNK_MB="1")
+    r = subprocess.run([sys.executable, "-c", _PACK_SCRIPT, root], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "PACK_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
