@@ -820,14 +820,28 @@ static bool narrow_bf16_ok(const rag_index* h, int k) {
 // instead of sending a score matrix through HBM -- from 2048 queries, where a workgroup's row range is long enough for the
 // thresholds to settle (10M x 768, k = 200: 4096 queries 589 ms by the segment walk, 514 ms here; 512 queries 78.5 against 84.1,
 // 1024 queries the same either way).
+//
+// Seeded thresholds: what makes k = 200 expensive inside the kernel is the start of a row range, where a query's threshold is
+// loose and every tile pushes and sorts hundreds of keys.  On a corpus of 2^20+ rows the first few segments (8 x 32768 rows) go
+// through the score-writing kernel and the per-segment selection first (the segment walk's first step, below); their k-th best
+// score per query is a lower bound of the final one and becomes the starting value of the query's shared threshold word, so the
+// selecting kernel then walks the whole corpus pushing only the handful of rows per range that beat it.  That makes the in-kernel
+// selection pay from 129 queries (wherever the batch takes the 256 x 256 shape) instead of 2048.
 constexpr int GEMM_BIG_MAX_K = 200;
 static bool gemm_big_shape(const rag_index* h, long long nq);
+static bool gemm_seeded(const rag_index* h, long long nq, int k) {
+    static const int on = env_int_g("RAG_GEMM_SEED", 1);            // measurement knob
+    return on && k > GEMM_MAX_K && k <= GEMM_BIG_MAX_K && !h->prefilter && h->n >= (1 << 20) && nq > 128 && gemm_big_shape(h, nq);
+}
+static size_t gemm_seed_workspace(const rag_index* h, long long nq, int k);
+static int gemm_seed_thresholds(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask, char* w,
+                                unsigned int* gthr, float* D, long long* I, hipStream_t s);
 bool gemm_topk_supported(const rag_index* h, long long nq, int k) {
     static const int min_nq = env_int_g("RAG_GEMM_MIN_NQ", 5);
     static const int big_max_k = std::min(GEMM_BIG_MAX_K, env_int_g("RAG_GEMM_BIG_MAX_K", GEMM_BIG_MAX_K));      // 64 switches it off
     if (!(h->kind == RAG_KIND_FLAT && (h->ld % GK) == 0 && h->n >= 1)) return false;
     static const int big_k_min_nq = env_int_g("RAG_GEMM_BIG_K_MIN_NQ", 2048);
-    if (k > GEMM_MAX_K && !(k <= big_max_k && nq >= big_k_min_nq && !h->prefilter && gemm_big_shape(h, nq))) return false;
+    if (k > GEMM_MAX_K && !(k <= big_max_k && (nq >= big_k_min_nq || gemm_seeded(h, nq, k)) && !h->prefilter && gemm_big_shape(h, nq))) return false;
     return nq >= min_nq || (nq >= 2 && narrow_bf16_ok(h, k));
 }
 
@@ -933,7 +947,8 @@ static bool gemm_big_shape(const rag_index* h, long long nq) {
 // bytes of workspace the gemm path needs after the padded queries
 size_t gemm_topk_workspace(const rag_index* h, long long nq, int k) {
     const GemmPlan p = gemm_plan(h, nq, k);
-    return p.cand_bytes + p.part_bytes + p.gthr_bytes + p.qb_bytes + p.margin_bytes + p.part16_bytes + (p.pref ? 256 : 0);
+    return p.cand_bytes + p.part_bytes + p.gthr_bytes + p.qb_bytes + p.margin_bytes + p.part16_bytes + (p.pref ? 256 : 0) +
+           (gemm_seeded(h, nq, k) ? gemm_seed_workspace(h, nq, k) : 0);
 }
 
 template <int RT, int QT, int NW, bool B16 = false>
@@ -1004,9 +1019,13 @@ int gemm_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float
     a.cand = reinterpret_cast<u64*>(w);
     a.part = reinterpret_cast<u64*>(w + p.cand_bytes);
     static const int share_thr = env_int_g("RAG_GEMM_SHARE_THR", 1);
-    if (share_thr && p.S > 1) {
+    const bool seeded = gemm_seeded(h, nq, k);
+    if ((share_thr && p.S > 1) || seeded) {
         a.gthr = reinterpret_cast<unsigned int*>(w + p.cand_bytes + p.part_bytes);
         RAG_HIP_CHECK(hipMemsetAsync(a.gthr, 0, (size_t)nq * sizeof(unsigned int), s));
+    }
+    if (seeded) {       // (never together with the bf16 first pass: its workspace follows the threshold words directly)
+        if (int rc = gemm_seed_thresholds(h, nq, qbuf, k, min_score, mask, w + p.cand_bytes + p.part_bytes + p.gthr_bytes, a.gthr, D, I, s)) return rc;
     }
     MergeArgs m = {};
     m.keys = a.part;
@@ -1084,7 +1103,7 @@ int gemm_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float
     if (rc) return rc;
     if (int rc2 = profile_end(h, s)) return rc2;
     RAG_HIP_CHECK(launch_merge_keys(m, nq, s));
-    h->last_path = "gemm";
+    h->last_path = seeded ? "gemm-seeded" : "gemm";
     return RAG_OK;
 }
 
@@ -1317,6 +1336,84 @@ int gemm_segments_search(rag_index* h, long long nq, const float* qbuf, int k, f
     }
     if (int rc = profile_end(h, s)) return rc;
     h->last_path = "gemm-segments";
+    return RAG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Starting thresholds for the selecting kernel at k above 64 (gemm_seeded): the first `segs` segments of the corpus through
+// the score-writing kernel, the per-segment selection and one merge, a chunk of queries at a time; a query's k-th best score
+// among those rows (mask and min_score applied: only rows that may be reported count) goes to its threshold word, 0 = "none"
+// where fewer than k such rows exist.  D / I are used as scratch for the merged lists (the search overwrites them).
+struct SeedPlan {
+    long long qc, segs, rows;
+    size_t scores_bytes, d_bytes, i_bytes, keys_bytes;
+};
+static SeedPlan seed_plan(const rag_index* h, long long nq, int k) {
+    static const long long seed_segs = std::max(1, env_int_g("RAG_GEMM_SEED_SEGS", 8));      // measurement knob
+    SeedPlan p;
+    p.qc = std::min<long long>(nq, 4096);
+    // a score matrix of at most 2 GB
+    p.segs = std::max<long long>(1, std::min<long long>(seed_segs, ((long long)2 << 30) / (p.qc * SCORES_MAX_ROWS * (long long)sizeof(float))));
+    p.rows = std::min<long long>(h->n, p.segs * SCORES_MAX_ROWS);
+    p.segs = (p.rows + SCORES_MAX_ROWS - 1) / SCORES_MAX_ROWS;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    p.scores_bytes = al((size_t)p.qc * p.rows * sizeof(float));
+    p.d_bytes = al((size_t)p.segs * p.qc * k * sizeof(float));
+    p.i_bytes = al((size_t)p.segs * p.qc * k * sizeof(long long));
+    p.keys_bytes = al((size_t)p.segs * p.qc * k * sizeof(u64));
+    return p;
+}
+static size_t gemm_seed_workspace(const rag_index* h, long long nq, int k) {
+    const SeedPlan p = seed_plan(h, nq, k);
+    return p.scores_bytes + p.d_bytes + p.i_bytes + p.keys_bytes;
+}
+__global__ void seed_thresholds_kernel(const float* D, const long long* I, long long nq, int k, unsigned int* gthr) {
+    const long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (q < nq) gthr[q] = I[(size_t)q * k + k - 1] >= 0 ? f32_ordered(D[(size_t)q * k + k - 1]) : 0u;
+}
+static int gemm_seed_thresholds(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask, char* w,
+                                unsigned int* gthr, float* D, long long* I, hipStream_t s) {
+    const SeedPlan p = seed_plan(h, nq, k);
+    float* scores = reinterpret_cast<float*>(w);
+    float* Dseg = reinterpret_cast<float*>(w + p.scores_bytes);
+    long long* Iseg = reinterpret_cast<long long*>(w + p.scores_bytes + p.d_bytes);
+    u64* keys = reinterpret_cast<u64*>(w + p.scores_bytes + p.d_bytes + p.i_bytes);
+    for (long long q0 = 0; q0 < nq; q0 += p.qc) {
+        const long long qc = std::min(p.qc, nq - q0);
+        const int QT = qc >= 512 ? 256 : qc > 64 ? 128 : qc > 32 ? 64 : 32;
+        const int RT = QT == 32 ? 256 : QT == 64 ? 128 : QT;
+        GemmArgs a = {};
+        a.X = h->X;
+        a.Q = qbuf + (size_t)q0 * h->ld;
+        a.n = p.rows;
+        a.ntiles = (p.rows + RT - 1) / RT;
+        a.nq = (int)qc;
+        a.ld = h->ld;
+        a.k = k;
+        a.nqb = (int)((qc + QT - 1) / QT);
+        a.nqb_pad = a.nqb;
+        a.S = (int)std::max<long long>(1, std::min<long long>(a.ntiles, (QT == 256 ? 256 : 512) / a.nqb_pad));
+        a.gq = 0;
+        a.outc = k;
+        a.trig = gemm_trig(RT, QT, GEMM_MAX_K);
+        a.scores = scores;
+        const int grid = a.nqb_pad * a.S;
+        int rc;
+        if (QT == 256) rc = launch_gemm_store<256, 256, 8>(a, grid, h->device, s);
+        else if (QT == 128) rc = launch_gemm_store<128, 128, 4>(a, grid, h->device, s);
+        else if (QT == 64) rc = launch_gemm_store<128, 64, 4>(a, grid, h->device, s);
+        else rc = launch_gemm_store<256, 32, 4>(a, grid, h->device, s);
+        if (rc) return rc;
+        const size_t lstride = (size_t)qc * k;
+        if (int rc2 = direct_select_segments(qc, p.rows, SCORES_MAX_ROWS, k, min_score, mask, nullptr, 0, scores, Dseg, Iseg,
+                                             (long long)lstride, nullptr, 0, s))
+            return rc2;
+        float* Dq = D + (size_t)q0 * k;
+        long long* Iq = I + (size_t)q0 * k;
+        if (int rc3 = merge_lists_device((int)p.segs, qc, k, Dseg, (long long)lstride, Iseg, (long long)lstride, Dq, Iq, keys, s)) return rc3;
+        hipLaunchKernelGGL(seed_thresholds_kernel, dim3((unsigned)((qc + 255) / 256)), dim3(256), 0, s, Dq, Iq, qc, k, gthr + q0);
+        RAG_HIP_CHECK(hipGetLastError());
+    }
     return RAG_OK;
 }
 

@@ -152,7 +152,11 @@ def test_scores_path_matches_oracle(n, d, nq, k):
                                        (70_001, 64, 2, 65), (40_000, 96, 5, 1000),
                                        # rows of a multiple of 128 floats under up to 32 queries: the register-streaming kernel writes the scores
                                        (32 * 32_768 + 17, 128, 6, 70), (150_001, 768, 8, 200), (90_000, 384, 20, 100), (70_000, 256, 32, 65),
-                                       (1_030, 128, 2, 100), (140_000, 1024, 17, 80)])
+                                       (1_030, 128, 2, 100), (140_000, 1024, 17, 80),
+                                       # 2^20+ rows under batches that take the 256 x 256 shape, k <= 200: the selecting kernel with its
+                                       # thresholds seeded from the first 8 segments (256, 450 and 1030 queries; 300 queries walk the segments)
+                                       (1_048_576 + 4_099, 32, 256, 200), (1_050_000, 32, 450, 65), (1_060_000, 32, 1030, 100),
+                                       (1_048_576, 64, 300, 200), (1_048_576, 32, 2050, 200)])
 def test_segments_path_matches_oracle(n, d, nq, k):
     """k above 64 with 2 or more queries: the corpus is walked in segments of 32768 rows (score matrix on the matrix
     cores, one selection workgroup per query and segment, several segments per launch under small batches) and the
@@ -187,4 +191,38 @@ def test_segments_path_matches_oracle(n, d, nq, k):
     _check(D, I, X, Q, k, ids=ids, row_mask=alive)
     D2, I2 = idx.search(Q, k)
     assert np.array_equal(D, D2) and np.array_equal(I, I2)
+    idx.close()
+
+
+@pytest.mark.parametrize("nq,k", [(256, 200), (1024, 100)])
+def test_seeded_thresholds_on_adversarial_order(nq, k):
+    """k above 64 on 2^20+ rows: the selecting kernel starts from thresholds taken from the first 8 segments (path
+    "gemm-seeded").  Rows sorted by increasing score for one query make that starting value useless for it (every later
+    row beats it: the buffers must compact, never overflow); a block of duplicates lies across the end of the seeding rows;
+    a mask that removes the best seeding rows must not raise a threshold above what the allowed rows reach."""
+    from rag_amd import DeviceIndex
+    rng = np.random.default_rng(nq + k)
+    n, d = (1 << 20) + 5_000, 32
+    X = _unit(rng, n, d)
+    Q = _unit(rng, nq, d)
+    order = np.argsort(X @ Q[0], kind="stable")
+    X = np.ascontiguousarray(X[order])
+    edge = 8 * 32_768
+    X[edge - 3: edge + 4] = X[11]
+    Q[1] = X[11]
+    Q[2] = X[100]
+    X[200_000:200_300] = X[100] * np.float32(0.999)       # 300 near-copies of a seeding row ...
+    idx = DeviceIndex(d, metric="ip")
+    idx.add(X)
+    D, I = idx.search(Q, k)
+    assert idx.last_path == "gemm-seeded"
+    _check(D, I, X, Q, k)
+    assert I[1, :8].tolist() == [11] + list(range(edge - 3, edge + 4))
+    mask = np.ones(n, np.uint8)
+    mask[200_000:200_300] = 0                              # ... masked out: they may not count towards query 2's threshold
+    mask[100] = 0
+    mask[rng.uniform(size=n) < 0.5] = 0
+    D, I = idx.search(Q, k, row_mask=mask, min_score=0.3)
+    assert idx.last_path == "gemm-seeded"
+    _check(D, I, X, Q, k, row_mask=mask, min_score=0.3)
     idx.close()
