@@ -823,19 +823,33 @@ static bool narrow_bf16_ok(const rag_index* h, int k) {
 //
 // Seeded thresholds: what makes k = 200 expensive inside the kernel is the start of a row range, where a query's threshold is
 // loose and every tile pushes and sorts hundreds of keys.  On a corpus of 2^20+ rows the first few segments (8 x 32768 rows) go
-// through the score-writing kernel and the per-segment selection first (the segment walk's first step, below); their k-th best
-// score per query is a lower bound of the final one and becomes the starting value of the query's shared threshold word, so the
+// through the score-writing kernel first; a lower bound of their k-th best score per query (gemm_seed_thresholds, below) is a
+// lower bound of the final one and becomes the starting value of the query's shared threshold word, so the
 // selecting kernel then walks the whole corpus pushing only the handful of rows per range that beat it.  That makes the in-kernel
 // selection pay from 129 queries (wherever the batch takes the 256 x 256 shape) instead of 2048.
 constexpr int GEMM_BIG_MAX_K = 200;
 static bool gemm_big_shape(const rag_index* h, long long nq);
-static bool gemm_seeded(const rag_index* h, long long nq, int k) {
-    static const int on = env_int_g("RAG_GEMM_SEED", 1);            // measurement knob
-    return on && k > GEMM_MAX_K && k <= GEMM_BIG_MAX_K && !h->prefilter && h->n >= (1 << 20) && nq > 128 && gemm_big_shape(h, nq);
+// The same step pays at k <= 64 on a short corpus under a large batch (32768 < rows < 2^21, 1024+ queries), where a workgroup's
+// whole row range is a few dozen tiles and its first tile alone pushes and sorts a key per row and query: there the first 4096
+// rows seed the thresholds (4096 queries: 100k x 384 3.31 -> 2.86 ms, 400k x 384 10.8 -> 10.3, 1M x 768 47.2 -> 46.5; at 10M x 768
+// the step gains 0.1 % and is left out).
+constexpr long long SEED_SEG_ROWS = 32768;
+static long long gemm_seed_rows(const rag_index* h, long long nq, int k) {        // 0: the thresholds start open
+    static const int on = env_int_g("RAG_GEMM_SEED", 1);            // measurement knobs
+    static const long long seed_segs = std::max(1, env_int_g("RAG_GEMM_SEED_SEGS", 8));
+    static const long long short_rows = env_int_g("RAG_GEMM_SEED_SHORT_ROWS", 4096);      // 0 switches the short-corpus case off
+    static const int short_min_nq = env_int_g("RAG_GEMM_SEED_SHORT_MIN_NQ", 1024);
+    if (!on || h->prefilter) return 0;
+    if (k > GEMM_MAX_K)
+        return (k <= GEMM_BIG_MAX_K && h->n >= (1 << 20) && nq > 128 && gemm_big_shape(h, nq)) ? seed_segs * SEED_SEG_ROWS : 0;
+    static const long long short_max_n = env_int_g("RAG_GEMM_SEED_SHORT_MAX_N", 1 << 21);
+    if (short_rows > 0 && h->n < short_max_n && h->n > 32768 && nq >= short_min_nq) return std::min<long long>(short_rows, SEED_SEG_ROWS);
+    return 0;
 }
+static bool gemm_seeded(const rag_index* h, long long nq, int k) { return gemm_seed_rows(h, nq, k) > 0; }
 static size_t gemm_seed_workspace(const rag_index* h, long long nq, int k);
 static int gemm_seed_thresholds(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask, char* w,
-                                unsigned int* gthr, float* D, long long* I, hipStream_t s);
+                                unsigned int* gthr, hipStream_t s);
 bool gemm_topk_supported(const rag_index* h, long long nq, int k) {
     static const int min_nq = env_int_g("RAG_GEMM_MIN_NQ", 5);
     static const int big_max_k = std::min(GEMM_BIG_MAX_K, env_int_g("RAG_GEMM_BIG_MAX_K", GEMM_BIG_MAX_K));      // 64 switches it off
@@ -1025,7 +1039,7 @@ int gemm_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float
         RAG_HIP_CHECK(hipMemsetAsync(a.gthr, 0, (size_t)nq * sizeof(unsigned int), s));
     }
     if (seeded) {       // (never together with the bf16 first pass: its workspace follows the threshold words directly)
-        if (int rc = gemm_seed_thresholds(h, nq, qbuf, k, min_score, mask, w + p.cand_bytes + p.part_bytes + p.gthr_bytes, a.gthr, D, I, s)) return rc;
+        if (int rc = gemm_seed_thresholds(h, nq, qbuf, k, min_score, mask, w + p.cand_bytes + p.part_bytes + p.gthr_bytes, a.gthr, s)) return rc;
     }
     MergeArgs m = {};
     m.keys = a.part;
@@ -1340,44 +1354,63 @@ int gemm_segments_search(rag_index* h, long long nq, const float* qbuf, int k, f
 }
 
 // ---------------------------------------------------------------------------------------------
-// Starting thresholds for the selecting kernel at k above 64 (gemm_seeded): the first `segs` segments of the corpus through
-// the score-writing kernel, the per-segment selection and one merge, a chunk of queries at a time; a query's k-th best score
-// among those rows (mask and min_score applied: only rows that may be reported count) goes to its threshold word, 0 = "none"
-// where fewer than k such rows exist.  D / I are used as scratch for the merged lists (the search overwrites them).
+// Starting thresholds for the selecting kernel (gemm_seed_rows): the first rows of the corpus go through the score-writing
+// kernel, a chunk of queries at a time, and one workgroup per query takes a lower bound of the k-th best score among them: every
+// thread keeps the best score of its share of the rows (mask and min_score applied: only rows that may be reported count), and the
+// k-th largest of those per-thread maxima has k distinct rows at or above it.  With many more threads than k that is close to
+// the k-th best itself (k = 10 over 256 threads: rank 10.2 on average; k = 200 over 1024 threads: rank 223).  Where fewer than k
+// threads saw a row the word stays 0 = "no threshold yet".
 struct SeedPlan {
-    long long qc, segs, rows;
-    size_t scores_bytes, d_bytes, i_bytes, keys_bytes;
+    long long qc, rows;
+    size_t scores_bytes;
 };
 static SeedPlan seed_plan(const rag_index* h, long long nq, int k) {
-    static const long long seed_segs = std::max(1, env_int_g("RAG_GEMM_SEED_SEGS", 8));      // measurement knob
+    static_assert(SEED_SEG_ROWS == SCORES_MAX_ROWS, "seeding rows are counted in segments of the selection kernel");
     SeedPlan p;
     p.qc = std::min<long long>(nq, 4096);
     // a score matrix of at most 2 GB
-    p.segs = std::max<long long>(1, std::min<long long>(seed_segs, ((long long)2 << 30) / (p.qc * SCORES_MAX_ROWS * (long long)sizeof(float))));
-    p.rows = std::min<long long>(h->n, p.segs * SCORES_MAX_ROWS);
-    p.segs = (p.rows + SCORES_MAX_ROWS - 1) / SCORES_MAX_ROWS;
-    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    p.scores_bytes = al((size_t)p.qc * p.rows * sizeof(float));
-    p.d_bytes = al((size_t)p.segs * p.qc * k * sizeof(float));
-    p.i_bytes = al((size_t)p.segs * p.qc * k * sizeof(long long));
-    p.keys_bytes = al((size_t)p.segs * p.qc * k * sizeof(u64));
+    const long long want = gemm_seed_rows(h, nq, k);
+    const long long cap_rows = std::max<long long>(SCORES_MAX_ROWS, ((long long)2 << 30) / (p.qc * (long long)sizeof(float)) / SCORES_MAX_ROWS * SCORES_MAX_ROWS);
+    p.rows = std::min<long long>(h->n, std::min(want, cap_rows));
+    p.scores_bytes = ((size_t)p.qc * p.rows * sizeof(float) + 255) & ~(size_t)255;
     return p;
 }
-static size_t gemm_seed_workspace(const rag_index* h, long long nq, int k) {
-    const SeedPlan p = seed_plan(h, nq, k);
-    return p.scores_bytes + p.d_bytes + p.i_bytes + p.keys_bytes;
+static size_t gemm_seed_workspace(const rag_index* h, long long nq, int k) { return seed_plan(h, nq, k).scores_bytes; }
+
+template <int NT>
+__global__ __launch_bounds__(NT) void seed_heads_kernel(const float* scores, long long rows, const uint8_t* mask, float min_score, int k,
+                                                        unsigned int* gthr) {
+    __shared__ __attribute__((aligned(16))) unsigned int heads[NT];
+    const int tid = threadIdx.x;
+    const float* sc = scores + (size_t)blockIdx.x * rows;
+    unsigned int best = 0u;
+#pragma unroll 8
+    for (long long r = tid; r < rows; r += NT) {
+        const float v = sc[r];
+        if (v >= min_score && (!mask || mask[r])) {
+            const unsigned int o = f32_ordered(v);
+            best = o > best ? o : best;
+        }
+    }
+    heads[tid] = best;
+    __syncthreads();
+    if (best == 0u) return;
+    int above = 0;                       // maxima that rank before this one (equal ones: the lower thread first)
+    for (int j = 0; j < NT; j += 4) {
+        const uint4 hj = *reinterpret_cast<const uint4*>(&heads[j]);
+        above += (hj.x > best || (hj.x == best && j + 0 < tid)) ? 1 : 0;
+        above += (hj.y > best || (hj.y == best && j + 1 < tid)) ? 1 : 0;
+        above += (hj.z > best || (hj.z == best && j + 2 < tid)) ? 1 : 0;
+        above += (hj.w > best || (hj.w == best && j + 3 < tid)) ? 1 : 0;
+    }
+    if (above == k - 1) gthr[blockIdx.x] = best;
 }
-__global__ void seed_thresholds_kernel(const float* D, const long long* I, long long nq, int k, unsigned int* gthr) {
-    const long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (q < nq) gthr[q] = I[(size_t)q * k + k - 1] >= 0 ? f32_ordered(D[(size_t)q * k + k - 1]) : 0u;
-}
+
+// gthr: zeroed by the caller
 static int gemm_seed_thresholds(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask, char* w,
-                                unsigned int* gthr, float* D, long long* I, hipStream_t s) {
+                                unsigned int* gthr, hipStream_t s) {
     const SeedPlan p = seed_plan(h, nq, k);
     float* scores = reinterpret_cast<float*>(w);
-    float* Dseg = reinterpret_cast<float*>(w + p.scores_bytes);
-    long long* Iseg = reinterpret_cast<long long*>(w + p.scores_bytes + p.d_bytes);
-    u64* keys = reinterpret_cast<u64*>(w + p.scores_bytes + p.d_bytes + p.i_bytes);
     for (long long q0 = 0; q0 < nq; q0 += p.qc) {
         const long long qc = std::min(p.qc, nq - q0);
         const int QT = qc >= 512 ? 256 : qc > 64 ? 128 : qc > 32 ? 64 : 32;
@@ -1404,14 +1437,10 @@ static int gemm_seed_thresholds(rag_index* h, long long nq, const float* qbuf, i
         else if (QT == 64) rc = launch_gemm_store<128, 64, 4>(a, grid, h->device, s);
         else rc = launch_gemm_store<256, 32, 4>(a, grid, h->device, s);
         if (rc) return rc;
-        const size_t lstride = (size_t)qc * k;
-        if (int rc2 = direct_select_segments(qc, p.rows, SCORES_MAX_ROWS, k, min_score, mask, nullptr, 0, scores, Dseg, Iseg,
-                                             (long long)lstride, nullptr, 0, s))
-            return rc2;
-        float* Dq = D + (size_t)q0 * k;
-        long long* Iq = I + (size_t)q0 * k;
-        if (int rc3 = merge_lists_device((int)p.segs, qc, k, Dseg, (long long)lstride, Iseg, (long long)lstride, Dq, Iq, keys, s)) return rc3;
-        hipLaunchKernelGGL(seed_thresholds_kernel, dim3((unsigned)((qc + 255) / 256)), dim3(256), 0, s, Dq, Iq, qc, k, gthr + q0);
+        if (p.rows <= 8192 && k <= 64)
+            hipLaunchKernelGGL(seed_heads_kernel<256>, dim3((unsigned)qc), dim3(256), 0, s, scores, p.rows, mask, min_score, k, gthr + q0);
+        else
+            hipLaunchKernelGGL(seed_heads_kernel<1024>, dim3((unsigned)qc), dim3(1024), 0, s, scores, p.rows, mask, min_score, k, gthr + q0);
         RAG_HIP_CHECK(hipGetLastError());
     }
     return RAG_OK;
