@@ -158,6 +158,23 @@ def test_batch_4096_at_full_size(corpus):
     assert torch.equal(I2, Ig) and torch.equal(D2, Dg)
 
 
+@pytest.mark.parametrize("nq", [256, 1024])
+def test_top_200_batches_at_full_size(corpus, nq):
+    """Batches that ask for 200 hits (the fusion pipeline's over-fetch) at 10M x 768: the selecting kernel with its
+    thresholds seeded from the first 8 segments (path "gemm-seeded").  Every list checked on the device, block edges
+    against single-query scans at k = 200, no sampled row above a 200th score."""
+    torch, X, Q, idx, planted = corpus
+    import fullsize_checks as fc
+    Qbig, planted_big = EXTRA["Qbig"], EXTRA["planted_big"]
+    Dg, Ig = idx.search(Qbig[:nq], 200)
+    assert idx.last_path == "gemm-seeded"
+    fc.check_batch_answer(torch, X, Qbig[:nq], Dg, Ig, planted_big[:nq])
+    fc.check_against_single_scans(torch, idx, Qbig[:nq], Dg, Ig, fc.block_edges(nq), 200)
+    fc.check_no_sampled_row_beats_the_kth(torch, X, Qbig[:nq], Dg, Ig, [0, 100, nq - 1])
+    D2, I2 = idx.search(Qbig[:nq], 200)
+    assert torch.equal(I2, Ig) and torch.equal(D2, Dg)
+
+
 def test_bf16_first_pass_returns_the_fp32_answer(corpus):
     """Opt-in bf16 first pass at full size: one query (scan of the bf16 rows) and 1100 queries
     (bf16 MFMA pass) give the ids of the fp32 paths."""
