@@ -1509,6 +1509,64 @@ __global__ void lm_fill_kernel(const long long* lists, long long npairs, int npr
 
 constexpr int LM_GRID = 512;      // persistent workgroups of the list-major scan (2 per CU)
 
+// Starting thresholds of the list scan.  A (query, list) pair begins with an open threshold, so its first rows are all pushed
+// and sorted -- 64 times per query, although nearly every hit comes from the query's nearest lists.  One workgroup per query
+// scores the first rows of the query's first list and publishes a lower bound of their k-th best score in the query's shared
+// threshold word, which every work item reads when it starts.  The bound must hold for the scores the scan kernel computes (on
+// the matrix cores, in another summation order): two fp32 sums of the same `ld` products differ by at most
+// 2 ld 2^-24 sum|x_i q_i|, which is subtracted.  Rows a mask removes do not count.
+constexpr int IVF_SEED_MAX = 64;
+__global__ __launch_bounds__(256) void ivf_seed_kernel(const float* X, const float* Q, const long long* coarse_lists, int nprobe,
+                                                       const long long* list_begin, const long long* row_alias, const uint8_t* mask,
+                                                       const uint8_t* mask2, int ld, int k, int rows_max, unsigned int* gthr) {
+    __shared__ unsigned int sc[IVF_SEED_MAX];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long q = blockIdx.x;
+    const long long l = coarse_lists[q * nprobe];
+    if (l < 0) return;
+    const long long lo = list_begin[l];
+    const long long len = list_begin[l + 1] - lo;
+    const int n = (int)(len < rows_max ? len : rows_max);
+    if (n < k) return;
+    const f4* q4 = reinterpret_cast<const f4*>(Q + (size_t)q * ld);
+    const int ld4 = ld / 4;
+    // 16 lanes per row, 16 rows per pass of the workgroup: the loads of a lane are independent of each other
+    const int sub = lane & 15;
+    for (int r = wave * 4 + (lane >> 4); r < ((n + 15) & ~15); r += 16) {
+        const long long row = lo + (r < n ? r : n - 1);
+        const f4* x4 = reinterpret_cast<const f4*>(X + (size_t)row * ld);
+        float dot = 0.f, mag = 0.f;
+#pragma unroll 4
+        for (int c = sub; c < ld4; c += 16) {
+            const f4 x = x4[c], w = q4[c];
+            dot = fmaf(x[0], w[0], dot); mag += fabsf(x[0] * w[0]);
+            dot = fmaf(x[1], w[1], dot); mag += fabsf(x[1] * w[1]);
+            dot = fmaf(x[2], w[2], dot); mag += fabsf(x[2] * w[2]);
+            dot = fmaf(x[3], w[3], dot); mag += fabsf(x[3] * w[3]);
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            dot += __shfl_xor(dot, off, 64);
+            mag += __shfl_xor(mag, off, 64);
+        }
+        if (sub == 0 && r < n) {
+            const long long shown = row_alias ? row_alias[row] : row;        // masks count rows in insertion order
+            const bool ok = (!mask || mask[shown]) && (!mask2 || mask2[shown]);
+            const float v = dot - 1.5e-7f * (float)ld * mag;
+            sc[r] = (ok && v == v) ? f32_ordered(v) : 0u;
+        }
+    }
+    __syncthreads();
+    if (tid < n) {
+        const unsigned int mine = sc[tid];
+        if (mine != 0u) {
+            int above = 0;
+            for (int j = 0; j < n; ++j) above += (sc[j] > mine || (sc[j] == mine && j < tid)) ? 1 : 0;
+            if (above == k - 1) gthr[q] = mine;
+        }
+    }
+}
+
 static size_t lm_align(size_t b) { return (b + 255) & ~(size_t)255; }
 // candidate buffers of whichever of the two list-scan kernels runs
 static size_t lm_cand_bytes() { return std::max((size_t)LM_GRID * 32 * gemm_capq(256, 32) * sizeof(u64), lm_align(ivf_lists_cand_bytes())); }
@@ -1590,6 +1648,12 @@ int ivf_listmajor_scan(rag_index* h, long long nq, const float* qbuf, int k, flo
         ls.row_alias = v.orig_dev;
         ls.ld = h->ld;
         ls.k = k;
+        static const int seed_rows = std::min(IVF_SEED_MAX, env_int_g("RAG_IVF_SEED_ROWS", 32));      // 0 switches the seeding off (measurement knob)
+        if (seed_rows > 0) {
+            hipLaunchKernelGGL(ivf_seed_kernel, dim3((unsigned)nq), dim3(256), 0, s, h->X, qbuf, coarse_lists, nprobe, v.list_begin_dev, v.orig_dev,
+                               mask, mask2, h->ld, k, std::max(seed_rows, std::min(IVF_SEED_MAX, 2 * k)), gthr);
+            RAG_HIP_CHECK(hipGetLastError());
+        }
         if (int rc = profile_begin(h, s)) return rc;
         if (int rc = ivf_lists_launch(ls, s)) return rc;
         if (int rc = profile_end(h, s)) return rc;
