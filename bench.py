@@ -563,7 +563,10 @@ def leg_small_corpus(torch, args, device, rows=100_000, dim=384, k=10):
                          "note": "corpus resident in the 256 MiB Infinity Cache; HBM peak used as the denominator"},
             "batch_4096": {"value": 4096 * 5 / dtb, "unit": "queries/sec", "ms_per_step": dtb / 5 * 1e3,
                            "roofline": {"bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                        "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": None}}}
+                                        "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "kernel_ms": kb / max(lb, 1),
+                                        "whole_step_frac": 2.0 * 4096 * rows * dim / (dtb / 5) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                        "note": "frac = the selecting kernel alone; whole_step_frac = the same flops over the whole "
+                                                "step (with the launches that seed its thresholds, and the merge)"}}}
 
 
 def leg_ivf_share(torch, args, device, rows=12_500_000, dim=1024, nlist=16384, nprobe=64, k=10):
