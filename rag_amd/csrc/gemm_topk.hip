@@ -1406,6 +1406,17 @@ __global__ __launch_bounds__(NT) void seed_heads_kernel(const float* scores, lon
     if (above == k - 1) gthr[blockIdx.x] = best;
 }
 
+// the bound alone, for any table of [nq][rows] scores
+static int seed_thresholds_from_scores(const float* scores, long long rows, long long nq, const uint8_t* mask, float min_score, int k,
+                                unsigned int* gthr, hipStream_t s) {
+    if (rows <= 16384 && k <= 64)
+        hipLaunchKernelGGL(seed_heads_kernel<256>, dim3((unsigned)nq), dim3(256), 0, s, scores, rows, mask, min_score, k, gthr);
+    else
+        hipLaunchKernelGGL(seed_heads_kernel<1024>, dim3((unsigned)nq), dim3(1024), 0, s, scores, rows, mask, min_score, k, gthr);
+    RAG_HIP_CHECK(hipGetLastError());
+    return RAG_OK;
+}
+
 // gthr: zeroed by the caller
 static int gemm_seed_thresholds(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask, char* w,
                                 unsigned int* gthr, hipStream_t s) {
@@ -1437,11 +1448,7 @@ static int gemm_seed_thresholds(rag_index* h, long long nq, const float* qbuf, i
         else if (QT == 64) rc = launch_gemm_store<128, 64, 4>(a, grid, h->device, s);
         else rc = launch_gemm_store<256, 32, 4>(a, grid, h->device, s);
         if (rc) return rc;
-        if (p.rows <= 8192 && k <= 64)
-            hipLaunchKernelGGL(seed_heads_kernel<256>, dim3((unsigned)qc), dim3(256), 0, s, scores, p.rows, mask, min_score, k, gthr + q0);
-        else
-            hipLaunchKernelGGL(seed_heads_kernel<1024>, dim3((unsigned)qc), dim3(1024), 0, s, scores, p.rows, mask, min_score, k, gthr + q0);
-        RAG_HIP_CHECK(hipGetLastError());
+        if (int rc2 = seed_thresholds_from_scores(scores, p.rows, qc, mask, min_score, k, gthr + q0, s)) return rc2;
     }
     return RAG_OK;
 }

@@ -226,3 +226,39 @@ def test_seeded_thresholds_on_adversarial_order(nq, k):
     assert idx.last_path == "gemm-seeded"
     _check(D, I, X, Q, k, row_mask=mask, min_score=0.3)
     idx.close()
+
+
+@pytest.mark.parametrize("nq,k", [(7, 10), (16, 32), (32, 10), (20, 1)])
+def test_narrow_kernel_with_sample_launch(nq, k):
+    """5..32 queries on 2^20+ rows: the register-streaming kernel starts from thresholds its first launch took from the
+    leading 32768 rows.  Rows sorted by increasing score for query 0 (its starting value is useless), duplicates inside
+    the leading rows, a mask that removes the best of them, fewer allowed rows than k for the last case."""
+    from rag_amd import DeviceIndex
+    rng = np.random.default_rng(100 * nq + k)
+    n, d = (1 << 20) + 3_000, 128
+    X = _unit(rng, n, d)
+    Q = _unit(rng, nq, d)
+    order = np.argsort(X @ Q[0], kind="stable")
+    X = np.ascontiguousarray(X[order])
+    X[8_190:8_195] = X[3]
+    Q[1] = X[3]
+    Q[2] = X[50]
+    X[4_000:4_040] = X[50] * np.float32(0.999)
+    idx = DeviceIndex(d, metric="ip")
+    idx.add(X)
+    D, I = idx.search(Q, k)
+    assert idx.last_path == "narrow"
+    _check(D, I, X, Q, k)
+    if k >= 6:
+        assert I[1, :6].tolist() == [3] + list(range(8_190, 8_195))
+    mask = np.ones(n, np.uint8)
+    mask[4_000:4_040] = 0
+    mask[50] = 0
+    mask[rng.uniform(size=n) < 0.5] = 0
+    D, I = idx.search(Q, k, row_mask=mask, min_score=0.2)
+    _check(D, I, X, Q, k, row_mask=mask, min_score=0.2)
+    few = np.zeros(n, np.uint8)
+    few[[5, 9_000, 500_000]] = 1
+    D, I = idx.search(Q, k, row_mask=few)
+    _check(D, I, X, Q, k, row_mask=few)
+    idx.close()
