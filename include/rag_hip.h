@@ -169,8 +169,8 @@ int rag_index_search_segments_fused(rag_index_t* h, int64_t nq, const float* q, 
                                     int32_t* n_out);
 /* which kernel path the last search on this index used: "none", "empty", "scan" (1-4 queries, HBM scan), "direct" (1-4
  * queries over <= 32768 rows), "narrow" (5-32 queries, one HBM-rate pass on the matrix cores), "gemm" (the selecting
- * matrix-core kernel), "gemm-seeded" (the same for k in 65..200 on 2^20+ rows: thresholds start from the k-th best of the first
- * segments), "gemm-scores" (large batch over a short corpus: score matrix + selection), "gemm-segments" (other batches
+ * matrix-core kernel), "gemm-seeded" (the same with thresholds that start from a bound taken from the leading rows: k in 65..200 on 2^20+ rows,
+ * large batches over short corpora), "gemm-scores" (large batch over a short corpus: score matrix + selection), "gemm-segments" (other batches
  * with k above 64: the same per 32768-row segment), "scan-bf16" / "gemm-bf16" (opt-in bf16 first pass + fp32 re-score),
  * "ivf" (per-query list scan), "ivf-listmajor" (batched list scan on the matrix cores), "segments", "segments-fused" */
 const char* rag_index_last_path(const rag_index_t* h);

@@ -79,17 +79,17 @@ constexpr int GEMM_MAX_K = 64;
 // block), so they tighten early and often; the square shape streams long ranges and rarely compacts.
 // The narrow shapes trigger at 64 keys for k <= 32 and at 128 above (a trigger below 2k would
 // compact after every tile); their buffers are sized for the larger one.
-__host__ __device__ constexpr int gemm_trig_max(int RT, int QT) { return QT >= 128 ? RT : 128; }
+__host__ __device__ constexpr int gemm_trig_max(int RT, int QT) { return QT >= 128 ? 256 : 128; }
 // Wide shapes (QT >= 128): the threshold of a query only moves when its buffer is compacted, so a
 // late trigger leaves it stale -- with 256 the k-th best of the first 256 rows stood for the next 6000
 // rows and every tile pushed a dozen candidates per wave.  Triggering at about 3k keeps the threshold
 // within a factor of ~3 of the current one; the sort of a compaction then covers 64 or 128 keys.
 // The bf16 pass carries every key within the margin of the k-th best across a compaction (a few times k
 // on unstructured data), so it triggers later.
-// k above 64 (the 256 x 256 shape only, up to GEMM_BIG_MAX_K): the trigger is the buffer's whole first half, 256 keys, which has
-// to stay well above k -- a buffer cut to k keys that is past its trigger again after a push would compact at every tile.
+// k above 64 (the wide shapes only, up to GEMM_BIG_MAX_K): the trigger is 256 keys, which has to stay well above k -- a buffer
+// cut to k keys that is past its trigger again after a push would compact at every tile.  The buffers hold 256 + RT keys.
 __host__ __device__ constexpr int gemm_trig(int RT, int QT, int k, bool b16 = false) {
-    return QT >= 128 ? (b16 ? (k <= 16 ? 128 : RT) : (k <= 16 ? 32 : (k <= 32 ? 64 : (k <= 64 ? 128 : RT))))
+    return QT >= 128 ? (b16 ? (k <= 16 ? 128 : RT) : (k <= 16 ? 32 : (k <= 32 ? 64 : (k <= 64 ? 128 : 256))))
                      : (b16 ? 128 : (k <= 32 ? 64 : 128));
 }
 __host__ __device__ constexpr int gemm_capq(int RT, int QT) { return gemm_trig_max(RT, QT) + RT; }
@@ -826,7 +826,7 @@ static bool narrow_bf16_ok(const rag_index* h, int k) {
 // through the score-writing kernel first; a lower bound of their k-th best score per query (gemm_seed_thresholds, below) is a
 // lower bound of the final one and becomes the starting value of the query's shared threshold word, so the
 // selecting kernel then walks the whole corpus pushing only the handful of rows per range that beat it.  That makes the in-kernel
-// selection pay from 129 queries (wherever the batch takes the 256 x 256 shape) instead of 2048.
+// selection pay from 65 queries (the 128 x 128 and 256 x 256 shapes) instead of 2048.
 constexpr int GEMM_BIG_MAX_K = 200;
 static bool gemm_big_shape(const rag_index* h, long long nq);
 // The same step pays at k <= 64 on a short corpus under a large batch (32768 < rows < 2^21, 1024+ queries), where a workgroup's
@@ -841,7 +841,7 @@ static long long gemm_seed_rows(const rag_index* h, long long nq, int k) {      
     static const int short_min_nq = env_int_g("RAG_GEMM_SEED_SHORT_MIN_NQ", 1024);
     if (!on || h->prefilter) return 0;
     if (k > GEMM_MAX_K)
-        return (k <= GEMM_BIG_MAX_K && h->n >= (1 << 20) && nq > 128 && gemm_big_shape(h, nq)) ? seed_segs * SEED_SEG_ROWS : 0;
+        return (k <= GEMM_BIG_MAX_K && h->n >= (1 << 20) && nq > 64) ? seed_segs * SEED_SEG_ROWS : 0;     // 65+ queries: a wide shape
     static const long long short_max_n = env_int_g("RAG_GEMM_SEED_SHORT_MAX_N", 1 << 21);
     if (short_rows > 0 && h->n < short_max_n && h->n > 32768 && nq >= short_min_nq) return std::min<long long>(short_rows, SEED_SEG_ROWS);
     return 0;
@@ -855,7 +855,7 @@ bool gemm_topk_supported(const rag_index* h, long long nq, int k) {
     static const int big_max_k = std::min(GEMM_BIG_MAX_K, env_int_g("RAG_GEMM_BIG_MAX_K", GEMM_BIG_MAX_K));      // 64 switches it off
     if (!(h->kind == RAG_KIND_FLAT && (h->ld % GK) == 0 && h->n >= 1)) return false;
     static const int big_k_min_nq = env_int_g("RAG_GEMM_BIG_K_MIN_NQ", 2048);
-    if (k > GEMM_MAX_K && !(k <= big_max_k && (nq >= big_k_min_nq || gemm_seeded(h, nq, k)) && !h->prefilter && gemm_big_shape(h, nq))) return false;
+    if (k > GEMM_MAX_K && !(k <= big_max_k && !h->prefilter && (gemm_seeded(h, nq, k) || (nq >= big_k_min_nq && gemm_big_shape(h, nq))))) return false;
     return nq >= min_nq || (nq >= 2 && narrow_bf16_ok(h, k));
 }
 

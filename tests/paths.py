@@ -19,8 +19,8 @@ def flat_fp32_path(n, d, nq, k):
         return "gemm"
     big_shape = nq >= 1024 or (nq > 128 and n >= 1 << 20 and -(-nq // 256) * 256 == -(-nq // 128) * 128)
     big_shape = big_shape and not (32768 < n < 1 << 19)      # short corpora take the 128 x 128 shape
-    if big_shape and nq > 128 and n >= 1 << 20 and 64 < k <= 200 and ld % 32 == 0:
-        return "gemm-seeded"          # the same with thresholds seeded from the first segments: from 129 queries on 2^20+ rows
+    if nq > 64 and n >= 1 << 20 and 64 < k <= 200 and ld % 32 == 0:
+        return "gemm-seeded"          # the selecting kernel with thresholds seeded from the first segments: from 65 queries on 2^20+ rows
     if big_shape and nq >= 2048 and 64 < k <= 200 and ld % 32 == 0 and n >= 1:
         return "gemm"                 # the 256 x 256 shape carries up to 200 keys per query, from 2048 queries
     if nq >= 2 and 64 < k <= 1024 and ld % 32 == 0 and n >= 1024:

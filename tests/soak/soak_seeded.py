@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Randomised parity run of the searches that start from seeded thresholds (path "gemm-seeded": k <= 64 on short
+corpora under 1024+ queries, k in 65..200 on 2^20+ rows under 65+ queries) against the
+CPU oracle: unstructured and clustered rows (near ties), rows sorted by increasing score for one query, duplicate
+rows, masks, thresholds; every search issued twice (answers must repeat bit for bit).  CASES=first:last."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+from oracle import flat
+from rag_amd import DeviceIndex
+
+a, b = os.environ.get("CASES", "0:24").split(":")
+bad = 0
+t0 = time.time()
+for case in range(int(a), int(b)):
+    rng = np.random.default_rng(9000 + case)
+    if case % 2 == 0:                                    # short corpus, k <= 64
+        n = int(rng.integers(32_769, 300_000))
+        d = int(rng.choice([32, 64, 96]))
+        nq = int(rng.integers(1024, 2500))
+        k = int(rng.choice([1, 10, 32, 64]))
+    else:                                                # 2^20+ rows, k in 65..200, 65+ queries (128 x 128 and 256 x 256 shapes)
+        n = int(rng.integers(1 << 20, 1_200_000))
+        d = 32
+        nq = int(rng.choice([int(rng.integers(65, 257)), int(rng.integers(257, 1024)), int(rng.integers(1024, 1300))]))
+        k = int(rng.integers(65, 201))
+    kind = case % 3
+    if kind == 1:                                        # clustered: many near ties around every query
+        centres = rng.standard_normal((64, d)).astype(np.float32)
+        X = centres[rng.integers(0, 64, n)] + np.float32(0.05) * rng.standard_normal((n, d)).astype(np.float32)
+        Q = centres[rng.integers(0, 64, nq)] + np.float32(0.05) * rng.standard_normal((nq, d)).astype(np.float32)
+    else:
+        X = rng.standard_normal((n, d)).astype(np.float32)
+        Q = rng.standard_normal((nq, d)).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    if kind == 2:                                        # the seeding rows are the worst ones for query 0
+        X = np.ascontiguousarray(X[np.argsort(X @ Q[0], kind="stable")])
+    dup = rng.integers(0, n, 40)
+    X[dup[20:]] = X[dup[:20]]                            # exact duplicates anywhere
+    Q[1] = X[dup[0]]
+    mask = None
+    if case % 4 >= 2:
+        mask = (rng.uniform(size=n) < rng.choice([0.05, 0.5, 0.9])).astype(np.uint8)
+    min_score = float(rng.choice([-1e30, 0.1, 0.4])) if case % 5 == 0 else None
+    idx = DeviceIndex(d, metric="ip")
+    idx.add(X)
+    kw = {}
+    if mask is not None:
+        kw["row_mask"] = mask
+    if min_score is not None:
+        kw["min_score"] = min_score
+    D1, I1 = idx.search(Q, k, **kw)
+    path = idx.last_path
+    D2, I2 = idx.search(Q, k, **kw)
+    Dr, Ir = flat.flat_ip_search(X, Q, k, **kw)
+    diffs = flat.compare_topk(D1, I1, Dr, Ir, rtol=1e-5, atol=1e-6)
+    same = np.array_equal(I1, I2) and np.array_equal(D1, D2)
+    ok = diffs == [] and same and path == "gemm-seeded"
+    bad += 0 if ok else 1
+    print(f"case {case}: n={n} d={d} nq={nq} k={k} kind={kind} mask={mask is not None} min_score={min_score} path={path} "
+          f"{'ok' if ok else 'FAILED ' + str(diffs[:3]) + (' not repeatable' if not same else '')} ({time.time() - t0:.0f}s)", flush=True)
+    idx.close()
+print("SOAK", "FAILED" if bad else "ok", bad, flush=True)
+sys.exit(1 if bad else 0)

@@ -153,10 +153,11 @@ def test_scores_path_matches_oracle(n, d, nq, k):
                                        # rows of a multiple of 128 floats under up to 32 queries: the register-streaming kernel writes the scores
                                        (32 * 32_768 + 17, 128, 6, 70), (150_001, 768, 8, 200), (90_000, 384, 20, 100), (70_000, 256, 32, 65),
                                        (1_030, 128, 2, 100), (140_000, 1024, 17, 80),
-                                       # 2^20+ rows under batches that take the 256 x 256 shape, k <= 200: the selecting kernel with its
-                                       # thresholds seeded from the first 8 segments (256, 450 and 1030 queries; 300 queries walk the segments)
+                                       # 2^20+ rows under 65+ queries, k <= 200: the selecting kernel (128 x 128 and 256 x 256 shapes) with its
+                                       # thresholds seeded from the first 8 segments; 64 queries and k = 201 walk the segments
                                        (1_048_576 + 4_099, 32, 256, 200), (1_050_000, 32, 450, 65), (1_060_000, 32, 1030, 100),
-                                       (1_048_576, 64, 300, 200), (1_048_576, 32, 2050, 200)])
+                                       (1_048_576, 64, 300, 200), (1_048_576, 32, 2050, 200), (1_050_000, 32, 65, 100),
+                                       (1_060_000, 32, 128, 200), (1_050_000, 64, 600, 150), (1_048_576, 32, 64, 100), (1_048_576, 32, 300, 201)])
 def test_segments_path_matches_oracle(n, d, nq, k):
     """k above 64 with 2 or more queries: the corpus is walked in segments of 32768 rows (score matrix on the matrix
     cores, one selection workgroup per query and segment, several segments per launch under small batches) and the
@@ -194,7 +195,7 @@ def test_segments_path_matches_oracle(n, d, nq, k):
     idx.close()
 
 
-@pytest.mark.parametrize("nq,k", [(256, 200), (1024, 100)])
+@pytest.mark.parametrize("nq,k", [(256, 200), (1024, 100), (300, 200), (70, 128)])
 def test_seeded_thresholds_on_adversarial_order(nq, k):
     """k above 64 on 2^20+ rows: the selecting kernel starts from thresholds taken from the first 8 segments (path
     "gemm-seeded").  Rows sorted by increasing score for one query make that starting value useless for it (every later
