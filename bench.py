@@ -820,13 +820,17 @@ def main(argv=None):
     if not args.no_big:
         big = batch_leg(args.big_batch, args.big_steps or min(args.steps, 5))
         verified["batch_%d" % args.big_batch] = verify_batch(args.big_batch)
-    mid16 = None
+    mid16 = mid24 = None
     if args.mid_batch > 0:
         mid = batch_leg(min(args.mid_batch, args.big_batch), min(args.steps, 20))
         verified["batch_%d" % mid["batch"]] = verify_batch(mid["batch"])
         if args.mid_batch > 16:
             mid16 = batch_leg(16, min(args.steps, 20))
             verified["batch_16"] = verify_batch(16)
+        if args.mid_batch > 24:
+            # 17..32 queries take two 16-query column blocks: 24 queries cost what 32 cost
+            mid24 = batch_leg(24, min(args.steps, 20))
+            verified["batch_24"] = verify_batch(24)
     # opt-in mode, reported beside the fp32 numbers and never as `value`: bf16 first pass on the
     # matrix cores + fp32 re-scoring of the rows within the error margin (same answers)
     pre = pre1 = pre_mid = None
@@ -919,6 +923,8 @@ def main(argv=None):
             out["batch_%d" % mid["batch"]] = mid
         if mid16 is not None:
             out["batch_16"] = mid16
+        if mid24 is not None:
+            out["batch_24"] = mid24
         if pre is not None:
             out["batch_%d_bf16_first_pass" % args.big_batch] = pre
         if pre_mid is not None:
