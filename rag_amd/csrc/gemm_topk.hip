@@ -815,11 +815,11 @@ static bool narrow_bf16_ok(const rag_index* h, int k) {
 }
 
 // from 5 queries; with the bf16 first pass in the narrow shape from 2 (half a corpus pass instead of a whole one)
-// The 256 x 256 shape carries up to 200 keys per query (its candidate buffers hold 512, the trigger sits at 256): batches that
-// take that shape keep their selection in the kernel up to k = 200 -- the reference's largest request, limit * 2 with limit <= 100 --
-// instead of sending a score matrix through HBM -- from 2048 queries, where a workgroup's row range is long enough for the
-// thresholds to settle (10M x 768, k = 200: 4096 queries 589 ms by the segment walk, 514 ms here; 512 queries 78.5 against 84.1,
-// 1024 queries the same either way).
+// The wide shapes (128 x 128, 256 x 256) carry up to 200 keys per query (candidate buffers of 256 + RT keys, the trigger at 256):
+// they can keep the selection of a request up to k = 200 -- the reference's largest, limit * 2 with limit <= 100 -- in the kernel
+// instead of sending a score matrix through HBM.  With thresholds that start open this pays only from 2048 queries in the
+// 256 x 256 shape, where a workgroup's row range is long enough for them to settle (10M x 768, k = 200: 4096 queries 589 ms by the
+// segment walk, 514 ms here; 512 queries 78.5 against 84.1, 1024 queries the same either way).
 //
 // Seeded thresholds: what makes k = 200 expensive inside the kernel is the start of a row range, where a query's threshold is
 // loose and every tile pushes and sorts hundreds of keys.  On a corpus of 2^20+ rows the first few segments (8 x 32768 rows) go
