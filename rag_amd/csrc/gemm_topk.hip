@@ -1634,6 +1634,13 @@ int ivf_listmajor_scan(rag_index* h, long long nq, const float* qbuf, int k, flo
     m.rows_out = h->merge_rows_out;
     m.D = D;
     m.I = I;
+    // starting thresholds (either scan kernel reads a query's shared word when a work item starts / once per tile)
+    static const int seed_rows = std::min(IVF_SEED_MAX, env_int_g("RAG_IVF_SEED_ROWS", 32));      // 0 switches the seeding off (measurement knob)
+    if (seed_rows > 0 && share_thr && k <= IVF_SEED_MAX) {
+        hipLaunchKernelGGL(ivf_seed_kernel, dim3((unsigned)nq), dim3(256), 0, s, h->X, qbuf, coarse_lists, nprobe, v.list_begin_dev, v.orig_dev,
+                           mask, mask2, h->ld, k, std::max(seed_rows, std::min(IVF_SEED_MAX, 2 * k)), gthr);
+        RAG_HIP_CHECK(hipGetLastError());
+    }
     if (ivf_lists_kernel_ok(h, k)) {
         // the register-streaming kernel (ivf_lists.hip): 16-query column blocks, work items from a device queue
         ListScanArgs ls = {};
@@ -1655,12 +1662,6 @@ int ivf_listmajor_scan(rag_index* h, long long nq, const float* qbuf, int k, flo
         ls.row_alias = v.orig_dev;
         ls.ld = h->ld;
         ls.k = k;
-        static const int seed_rows = std::min(IVF_SEED_MAX, env_int_g("RAG_IVF_SEED_ROWS", 32));      // 0 switches the seeding off (measurement knob)
-        if (seed_rows > 0) {
-            hipLaunchKernelGGL(ivf_seed_kernel, dim3((unsigned)nq), dim3(256), 0, s, h->X, qbuf, coarse_lists, nprobe, v.list_begin_dev, v.orig_dev,
-                               mask, mask2, h->ld, k, std::max(seed_rows, std::min(IVF_SEED_MAX, 2 * k)), gthr);
-            RAG_HIP_CHECK(hipGetLastError());
-        }
         if (int rc = profile_begin(h, s)) return rc;
         if (int rc = ivf_lists_launch(ls, s)) return rc;
         if (int rc = profile_end(h, s)) return rc;
