@@ -438,7 +438,7 @@ def leg_pipeline(torch, index, Q, args, device, topn=200, final=10, nq=16):
         dtb = (time.perf_counter() - t0) / bsteps
         batch = {"value": B / dtb, "unit": "queries/sec", "batch": B, "steps": bsteps, "ms_per_step": dtb * 1e3,
                  "answered": int((out[2] > 0).sum().item()),
-                 "note": "one search of the whole batch (k = 200 in the selecting kernel, thresholds seeded from the first 8 segments of 32768 rows), "
+                 "note": "one search of the whole batch (k = 200 in the selecting kernel, thresholds seeded from the leading rows), "
                          "then fusion and MMR query by query on the same stream"}
     res = _pipeline_result(nsteps, dt, total_ms, scan_ms, topn, final, n, args, gbs, launches)
     if batch is not None:

@@ -822,7 +822,7 @@ static bool narrow_bf16_ok(const rag_index* h, int k) {
 // segment walk, 514 ms here; 512 queries 78.5 against 84.1, 1024 queries the same either way).
 //
 // Seeded thresholds: what makes k = 200 expensive inside the kernel is the start of a row range, where a query's threshold is
-// loose and every tile pushes and sorts hundreds of keys.  On a corpus of 2^20+ rows the first few segments (8 x 32768 rows) go
+// loose and every tile pushes and sorts hundreds of keys.  On a corpus of 2^20+ rows the first few segments (of 32768 rows) go
 // through the score-writing kernel first; a lower bound of their k-th best score per query (gemm_seed_thresholds, below) is a
 // lower bound of the final one and becomes the starting value of the query's shared threshold word, so the
 // selecting kernel then walks the whole corpus pushing only the handful of rows per range that beat it.  That makes the in-kernel
@@ -834,18 +834,7 @@ static bool gemm_big_shape(const rag_index* h, long long nq);
 // rows seed the thresholds (4096 queries: 100k x 384 3.31 -> 2.86 ms, 400k x 384 10.8 -> 10.3, 1M x 768 47.2 -> 46.5; at 10M x 768
 // the step gains 0.1 % and is left out).
 constexpr long long SEED_SEG_ROWS = 32768;
-static long long gemm_seed_rows(const rag_index* h, long long nq, int k) {        // 0: the thresholds start open
-    static const int on = env_int_g("RAG_GEMM_SEED", 1);            // measurement knobs
-    static const long long seed_segs = std::max(1, env_int_g("RAG_GEMM_SEED_SEGS", 8));
-    static const long long short_rows = env_int_g("RAG_GEMM_SEED_SHORT_ROWS", 4096);      // 0 switches the short-corpus case off
-    static const int short_min_nq = env_int_g("RAG_GEMM_SEED_SHORT_MIN_NQ", 1024);
-    if (!on || h->prefilter) return 0;
-    if (k > GEMM_MAX_K)
-        return (k <= GEMM_BIG_MAX_K && h->n >= (1 << 20) && nq > 64) ? seed_segs * SEED_SEG_ROWS : 0;     // 65+ queries: a wide shape
-    static const long long short_max_n = env_int_g("RAG_GEMM_SEED_SHORT_MAX_N", 1 << 21);
-    if (short_rows > 0 && h->n < short_max_n && h->n > 32768 && nq >= short_min_nq) return std::min<long long>(short_rows, SEED_SEG_ROWS);
-    return 0;
-}
+static long long gemm_seed_rows(const rag_index* h, long long nq, int k);        // 0: the thresholds start open
 static bool gemm_seeded(const rag_index* h, long long nq, int k) { return gemm_seed_rows(h, nq, k) > 0; }
 static size_t gemm_seed_workspace(const rag_index* h, long long nq, int k);
 static int gemm_seed_thresholds(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask, char* w,
@@ -956,6 +945,31 @@ static bool gemm_big_shape(const rag_index* h, long long nq) {
     if (force_qt) return force_qt == 256;
     const bool same_pad = nq > 128 && h->n >= (1 << 20) && (nq + 255) / 256 * 256 == (nq + 127) / 128 * 128;
     return (nq >= big_min_nq || same_pad) && !(!h->prefilter && h->n < (1 << 19) && h->n > 32768);
+}
+
+static long long gemm_seed_rows(const rag_index* h, long long nq, int k) {
+    static const int on = env_int_g("RAG_GEMM_SEED", 1);            // measurement knobs
+    static const long long seed_segs_env = env_int_g("RAG_GEMM_SEED_SEGS", 0);            // > 0: that many segments whatever the shape
+    static const long long short_rows = env_int_g("RAG_GEMM_SEED_SHORT_ROWS", 4096);      // 0 switches the short-corpus case off
+    static const int short_min_nq = env_int_g("RAG_GEMM_SEED_SHORT_MIN_NQ", 1024);
+    if (!on || h->prefilter) return 0;
+    if (k > GEMM_MAX_K) {
+        if (!(k <= GEMM_BIG_MAX_K && h->n >= (1 << 20) && nq > 64)) return 0;              // 65+ queries: a wide shape
+        // How many segments: a row range of R rows meets about R k / (seeding rows) rows above the seeded bound, and a
+        // query's buffer in a range should stay under its trigger (256 keys), so the seeding rows are R k / 128, in whole
+        // segments, at most 8 and at most an eighth of the corpus -- they are walked twice.  10M x 768, k = 200: 256 queries
+        // (ranges of 39k rows) 4 segments 30.0 ms, 8: 30.2; 1024 queries (156k rows) 4: 119.8, 8: 118.2, 16: 120.7;
+        // 3M rows, 1024 queries (47k) 1: 39.3, 2: 36.4, 4: 36.8, 8: 38.2; 1.25M rows, 256 queries (4.9k) 1: 4.80, 8: 5.41.
+        const GemmPlan p = gemm_plan(h, nq, k);
+        const long long range_rows = (h->n + p.S - 1) / p.S;
+        long long segs = (range_rows * k / 128 + SEED_SEG_ROWS - 1) / SEED_SEG_ROWS;
+        segs = std::max<long long>(1, std::min<long long>(std::min<long long>(8, segs), h->n / (8 * SEED_SEG_ROWS)));
+        if (seed_segs_env > 0) segs = seed_segs_env;
+        return segs * SEED_SEG_ROWS;
+    }
+    static const long long short_max_n = env_int_g("RAG_GEMM_SEED_SHORT_MAX_N", 1 << 21);
+    if (short_rows > 0 && h->n < short_max_n && h->n > 32768 && nq >= short_min_nq) return std::min<long long>(short_rows, SEED_SEG_ROWS);
+    return 0;
 }
 
 // bytes of workspace the gemm path needs after the padded queries

@@ -197,10 +197,11 @@ def test_segments_path_matches_oracle(n, d, nq, k):
 
 @pytest.mark.parametrize("nq,k", [(256, 200), (1024, 100), (300, 200), (70, 128)])
 def test_seeded_thresholds_on_adversarial_order(nq, k):
-    """k above 64 on 2^20+ rows: the selecting kernel starts from thresholds taken from the first 8 segments (path
-    "gemm-seeded").  Rows sorted by increasing score for one query make that starting value useless for it (every later
-    row beats it: the buffers must compact, never overflow); a block of duplicates lies across the end of the seeding rows;
-    a mask that removes the best seeding rows must not raise a threshold above what the allowed rows reach."""
+    """k above 64 on 2^20+ rows: the selecting kernel starts from thresholds taken from the first segments (1 to 8 of 32768
+    rows, by batch size; path "gemm-seeded").  Rows sorted by increasing score for one query make that starting value useless
+    for it (every later row beats it: the buffers must compact, never overflow); blocks of duplicates lie across the segment
+    ends where the seeding rows can stop; a mask that removes the best seeding rows must not raise a threshold above what the
+    allowed rows reach."""
     from rag_amd import DeviceIndex
     rng = np.random.default_rng(nq + k)
     n, d = (1 << 20) + 5_000, 32
@@ -210,7 +211,10 @@ def test_seeded_thresholds_on_adversarial_order(nq, k):
     X = np.ascontiguousarray(X[order])
     edge = 8 * 32_768
     X[edge - 3: edge + 4] = X[11]
+    for e in (32_768, 2 * 32_768, 4 * 32_768):
+        X[e - 2: e + 2] = X[12]
     Q[1] = X[11]
+    Q[3] = X[12]
     Q[2] = X[100]
     X[200_000:200_300] = X[100] * np.float32(0.999)       # 300 near-copies of a seeding row ...
     idx = DeviceIndex(d, metric="ip")
@@ -219,6 +223,7 @@ def test_seeded_thresholds_on_adversarial_order(nq, k):
     assert idx.last_path == "gemm-seeded"
     _check(D, I, X, Q, k)
     assert I[1, :8].tolist() == [11] + list(range(edge - 3, edge + 4))
+    assert I[3, :13].tolist() == [12] + [e + j for e in (32_768, 2 * 32_768, 4 * 32_768) for j in (-2, -1, 0, 1)]
     mask = np.ones(n, np.uint8)
     mask[200_000:200_300] = 0                              # ... masked out: they may not count towards query 2's threshold
     mask[100] = 0
