@@ -829,10 +829,11 @@ static bool narrow_bf16_ok(const rag_index* h, int k) {
 // selection pay from 65 queries (the 128 x 128 and 256 x 256 shapes) instead of 2048.
 constexpr int GEMM_BIG_MAX_K = 200;
 static bool gemm_big_shape(const rag_index* h, long long nq);
-// The same step pays at k <= 64 on a short corpus under a large batch (32768 < rows < 2^21, 1024+ queries), where a workgroup's
-// whole row range is a few dozen tiles and its first tile alone pushes and sorts a key per row and query: there the first 4096
-// rows seed the thresholds (4096 queries: 100k x 384 3.31 -> 2.86 ms, 400k x 384 10.8 -> 10.3, 1M x 768 47.2 -> 46.5; at 10M x 768
-// the step gains 0.1 % and is left out).
+// The same step pays at k <= 64, most where a workgroup's row range is short -- a short corpus under a large batch, or a batch of a
+// few dozen queries whose single query block is split 256 or 512 ways: the first tile of a range alone pushes and sorts a key per
+// row and query.  There 4096 to 16384 leading rows seed the thresholds (k = 10; 100k x 384: 4096 queries 3.31 -> 2.86 ms,
+// 256 queries 0.60 -> 0.34, 64 queries 0.28 -> 0.16; 1M x 768: 64 queries 1.24 -> 0.99, 512 queries 6.64 -> 6.36; 10M x 768:
+// 64 queries 9.50 -> 9.19, 256 queries 30.0 -> 28.9, 4096 queries 452.3 -> 450.2).
 constexpr long long SEED_SEG_ROWS = 32768;
 static long long gemm_seed_rows(const rag_index* h, long long nq, int k);        // 0: the thresholds start open
 static bool gemm_seeded(const rag_index* h, long long nq, int k) { return gemm_seed_rows(h, nq, k) > 0; }
@@ -950,8 +951,8 @@ static bool gemm_big_shape(const rag_index* h, long long nq) {
 static long long gemm_seed_rows(const rag_index* h, long long nq, int k) {
     static const int on = env_int_g("RAG_GEMM_SEED", 1);            // measurement knobs
     static const long long seed_segs_env = env_int_g("RAG_GEMM_SEED_SEGS", 0);            // > 0: that many segments whatever the shape
-    static const long long short_rows = env_int_g("RAG_GEMM_SEED_SHORT_ROWS", 4096);      // 0 switches the short-corpus case off
-    static const int short_min_nq = env_int_g("RAG_GEMM_SEED_SHORT_MIN_NQ", 1024);
+    static const long long rows_env = env_int_g("RAG_GEMM_SEED_ROWS", -1);                // k <= 64: 0 off, > 0 that many rows
+    static const int min_nq = env_int_g("RAG_GEMM_SEED_MIN_NQ", 33);
     if (!on || h->prefilter) return 0;
     if (k > GEMM_MAX_K) {
         if (!(k <= GEMM_BIG_MAX_K && h->n >= (1 << 20) && nq > 64)) return 0;              // 65+ queries: a wide shape
@@ -967,9 +968,16 @@ static long long gemm_seed_rows(const rag_index* h, long long nq, int k) {
         if (seed_segs_env > 0) segs = seed_segs_env;
         return segs * SEED_SEG_ROWS;
     }
-    static const long long short_max_n = env_int_g("RAG_GEMM_SEED_SHORT_MAX_N", 1 << 21);
-    if (short_rows > 0 && h->n < short_max_n && h->n > 32768 && nq >= short_min_nq) return std::min<long long>(short_rows, SEED_SEG_ROWS);
-    return 0;
+    // k <= 64: the same rule with this k's trigger (32 / 64 / 128 keys), between 4096 and 16384 rows and at most an eighth
+    // of the corpus; from 33 queries (the 128 x 64 shape and the wide ones) on more rows than the score-matrix path takes
+    if (rows_env == 0 || h->n <= SEED_SEG_ROWS || nq < min_nq) return 0;
+    const GemmPlan p = gemm_plan(h, nq, k);
+    const long long range_rows = (h->n + p.S - 1) / p.S;
+    long long rows = range_rows * k / std::max(1, gemm_trig(p.RT, p.QT, k) / 2);
+    rows = std::max<long long>(4096, std::min<long long>(16384, rows));
+    rows = std::min<long long>(rows, h->n / 8) / 256 * 256;
+    if (rows_env > 0) rows = std::min<long long>(rows_env, SEED_SEG_ROWS);
+    return rows;
 }
 
 // bytes of workspace the gemm path needs after the padded queries
@@ -1131,7 +1139,7 @@ int gemm_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float
     if (rc) return rc;
     if (int rc2 = profile_end(h, s)) return rc2;
     RAG_HIP_CHECK(launch_merge_keys(m, nq, s));
-    h->last_path = seeded ? "gemm-seeded" : "gemm";
+    h->last_path = (seeded && k > GEMM_MAX_K) ? "gemm-seeded" : "gemm";     // ("gemm-seeded": the seeding is what keeps k > 64 in this kernel)
     return RAG_OK;
 }
 

@@ -13,8 +13,6 @@ def flat_fp32_path(n, d, nq, k):
         nj = 1 if nq <= 16 else 2
         if ld * nj * 64 + 8 * 4096 + 8 * nj * 16 * 8 + 48 <= 160 * 1024:
             return "narrow"
-    if nq >= 1024 and k <= 64 and ld % 32 == 0 and 32768 < n < 1 << 21:
-        return "gemm-seeded"          # a short corpus under a large batch: thresholds seeded from the first 4096 rows
     if nq >= 5 and k <= 64 and ld % 32 == 0 and n >= 1:
         return "gemm"
     big_shape = nq >= 1024 or (nq > 128 and n >= 1 << 20 and -(-nq // 256) * 256 == -(-nq // 128) * 128)
