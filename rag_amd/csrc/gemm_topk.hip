@@ -952,7 +952,7 @@ static long long gemm_seed_rows(const rag_index* h, long long nq, int k) {
     static const int on = env_int_g("RAG_GEMM_SEED", 1);            // measurement knobs
     static const long long seed_segs_env = env_int_g("RAG_GEMM_SEED_SEGS", 0);            // > 0: that many segments whatever the shape
     static const long long rows_env = env_int_g("RAG_GEMM_SEED_ROWS", -1);                // k <= 64: 0 off, > 0 that many rows
-    static const int min_nq = env_int_g("RAG_GEMM_SEED_MIN_NQ", 33);
+    static const int min_nq = env_int_g("RAG_GEMM_SEED_MIN_NQ", 5);
     if (!on || h->prefilter) return 0;
     if (k > GEMM_MAX_K) {
         if (!(k <= GEMM_BIG_MAX_K && h->n >= (1 << 20) && nq > 64)) return 0;              // 65+ queries: a wide shape
@@ -969,7 +969,8 @@ static long long gemm_seed_rows(const rag_index* h, long long nq, int k) {
         return segs * SEED_SEG_ROWS;
     }
     // k <= 64: the same rule with this k's trigger (32 / 64 / 128 keys), between 4096 and 16384 rows and at most an eighth
-    // of the corpus; from 33 queries (the 128 x 64 shape and the wide ones) on more rows than the score-matrix path takes
+    // of the corpus; every batch this kernel takes (5+ queries) on more rows than the score-matrix path takes (1M x 96 under
+    // 32 queries 0.37 -> 0.16 ms; 10M x 768, k = 64, 32 queries 6.41 -> 5.82)
     if (rows_env == 0 || h->n <= SEED_SEG_ROWS || nq < min_nq) return 0;
     const GemmPlan p = gemm_plan(h, nq, k);
     const long long range_rows = (h->n + p.S - 1) / p.S;

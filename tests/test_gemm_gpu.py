@@ -35,6 +35,8 @@ def _check(D, I, X, Q, k, **kw):
     (30_000, 32, 130, 10), (30_000, 64, 1100, 10), (30_000, 96, 200, 20), (2_000, 32, 1024, 64),
     # 1M+ rows: the 256 x 256 shape also below 1024 queries where it pads the batch like 128 x 128 (200, 450), not at 300
     (1_050_000, 64, 200, 10), (1_048_576, 32, 450, 16), (1_050_001, 32, 300, 10),
+    # 5..32 queries outside the register-streaming kernel (rows of 96 floats, k above 32) on more than 32768 rows: seeded 256 x 32 shape
+    (70_000, 96, 9, 10), (100_000, 64, 32, 64), (40_000, 768, 20, 64), (33_000, 32, 5, 10),
     # query-block counts that no XCD grouping divides: 9 and 17 blocks of 256 (plain placement, no padding blocks), 12 blocks (groups of 4)
     (40_000, 64, 2304, 10), (36_000, 32, 4352, 10), (34_000, 64, 3000, 64)])
 def test_gemm_matches_oracle(n, d, nq, k):
