@@ -803,6 +803,15 @@ __global__ void queries_to_bf16_kernel(const float* Q, int ld, const int* maxnor
     if (lane == 63) margin[q] = 2.f * pref_err(ld) * __int_as_float(*maxnorm_bits) * sqrtf(ss) * 1.0001f + 1e-30f;
 }
 
+// The seeded threshold words hold a lower bound B of the exact k-th best score.  The bf16 pass keeps a row when its
+// approximate score is within the margin (2 delta) of the k-th best APPROXIMATE score, which is at least B - delta (the k
+// rows that score B or more exactly score B - delta or more approximately): the word becomes B - 3 delta.
+__global__ void pref_seed_adjust_kernel(unsigned int* gthr, const float* margin, long long nq) {
+    const long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const unsigned int b = gthr[q];
+    if (b != 0u) gthr[q] = f32_ordered(ordered_f32(b) - 1.5001f * margin[q]);
+}
 
 // bf16 first pass in the narrow 256 x 32 shape: one pass over half the bytes for up to 32 queries (k <= 32: the
 // keys within the margin of a range's k-th best -- about 2k on unstructured data -- have to fit the 128 keys a
@@ -953,9 +962,9 @@ static long long gemm_seed_rows(const rag_index* h, long long nq, int k) {
     static const long long seed_segs_env = env_int_g("RAG_GEMM_SEED_SEGS", 0);            // > 0: that many segments whatever the shape
     static const long long rows_env = env_int_g("RAG_GEMM_SEED_ROWS", -1);                // k <= 64: 0 off, > 0 that many rows
     static const int min_nq = env_int_g("RAG_GEMM_SEED_MIN_NQ", 5);
-    if (!on || h->prefilter) return 0;
+    if (!on) return 0;
     if (k > GEMM_MAX_K) {
-        if (!(k <= GEMM_BIG_MAX_K && h->n >= (1 << 20) && nq > 64)) return 0;              // 65+ queries: a wide shape
+        if (!(k <= GEMM_BIG_MAX_K && h->n >= (1 << 20) && nq > 64) || h->prefilter) return 0;      // 65+ queries: a wide shape
         // How many segments: a row range of R rows meets about R k / (seeding rows) rows above the seeded bound, and a
         // query's buffer in a range should stay under its trigger (256 keys), so the seeding rows are R k / 128, in whole
         // segments, at most 8 and at most an eighth of the corpus -- they are walked twice.  10M x 768, k = 200: 256 queries
@@ -973,6 +982,11 @@ static long long gemm_seed_rows(const rag_index* h, long long nq, int k) {
     // 32 queries 0.37 -> 0.16 ms; 10M x 768, k = 64, 32 queries 6.41 -> 5.82)
     if (rows_env == 0 || h->n <= SEED_SEG_ROWS || nq < min_nq) return 0;
     const GemmPlan p = gemm_plan(h, nq, k);
+    // The bf16 first pass takes the seed only in its 256 x 256 shape (10M x 768: 256 queries 6.67 -> 5.36 ms, 1024 queries
+    // 19.2 -> 17.4).  In the narrow shapes a range hands over at most 32..128 keys and relies on the thresholds other ranges
+    // publish when they compact; a seeded bound (3 delta below the sample's k-th best) is tight enough to stop the compactions
+    // and too loose for that hand-over, so the overflow flag went up and the fp32 kernel ran as well (8 queries 2.4 -> 7.8 ms).
+    if (p.pref && p.QT != 256) return 0;
     const long long range_rows = (h->n + p.S - 1) / p.S;
     long long rows = range_rows * k / std::max(1, gemm_trig(p.RT, p.QT, k) / 2);
     rows = std::max<long long>(4096, std::min<long long>(16384, rows));
@@ -1061,8 +1075,9 @@ int gemm_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float
         a.gthr = reinterpret_cast<unsigned int*>(w + p.cand_bytes + p.part_bytes);
         RAG_HIP_CHECK(hipMemsetAsync(a.gthr, 0, (size_t)nq * sizeof(unsigned int), s));
     }
-    if (seeded) {       // (never together with the bf16 first pass: its workspace follows the threshold words directly)
-        if (int rc = gemm_seed_thresholds(h, nq, qbuf, k, min_score, mask, w + p.cand_bytes + p.part_bytes + p.gthr_bytes, a.gthr, s)) return rc;
+    if (seeded) {       // (its score matrix lies behind everything the bf16 first pass keeps in the workspace)
+        char* seed_ws = w + p.cand_bytes + p.part_bytes + p.gthr_bytes + p.qb_bytes + p.margin_bytes + p.part16_bytes + (p.pref ? 256 : 0);
+        if (int rc = gemm_seed_thresholds(h, nq, qbuf, k, min_score, mask, seed_ws, a.gthr, s)) return rc;
     }
     MergeArgs m = {};
     m.keys = a.part;
@@ -1087,6 +1102,10 @@ int gemm_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float
         RAG_HIP_CHECK(hipMemsetAsync(flag, 0, 256, s));
         hipLaunchKernelGGL(queries_to_bf16_kernel, dim3((unsigned)nq), dim3(64), 0, s, qbuf, h->ld, h->xb_maxnorm, qb, margin);
         RAG_HIP_CHECK(hipGetLastError());
+        if (seeded) {
+            hipLaunchKernelGGL(pref_seed_adjust_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, a.gthr, margin, nq);
+            RAG_HIP_CHECK(hipGetLastError());
+        }
         GemmArgs b = a;
         b.X = reinterpret_cast<const float*>(h->Xb);
         b.Q = reinterpret_cast<const float*>(qb);
