@@ -61,6 +61,10 @@ constexpr int LS_CAP = LS_TRIG + LS_TILE;   // 64: one key per lane when sorted
 #define RAG_LISTS_DEPTH2 4
 #endif
 
+// issue order of a K step (measurement knob): 1 deals the next step's LDS operations between this step's MFMAs
+#ifndef RAG_LISTS_SGB
+#define RAG_LISTS_SGB 1
+#endif
 constexpr int LS_ROT = 4;              // K steps per rotation of the query images (one step's image per wave)
 
 // one K step of a wave's rows as loaded: [row group][8-row half], 16 bytes per lane each
@@ -307,6 +311,47 @@ __device__ __forceinline__ void ls_scan_rows(const ListScanArgs& a, f4* tp, f4* 
 #pragma unroll
             for (int u = 0; u < LS_ROT; ++u) {
                 const int slot = rr * LS_ROT + u, par = u & 1;
+                if (RAG_LISTS_SGB) {
+                    // The next step (of this tile, or step 0 of the next one: the ring holds it already) goes through the
+                    // transposer WHILE this step multiplies: its LDS operations are dealt between the MFMAs, one per PER of
+                    // them, so neither their issue nor their latency stands between two steps' MFMAs.
+                    constexpr int OPS_B = 8 + 2 * NCB, PER = 16 * NCB / OPS_B;
+                    transpose(ring[(slot + 1) % DEPTH], par ^ 1);
+                    if (u + 1 < LS_ROT) read_b(buf, u + 1, par ^ 1);
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+#pragma unroll
+                            for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                                for (int cb = 0; cb < NCB; ++cb)
+                                    acc[rg][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[par][rg][m][v], bf[par][m][cb][v], acc[rg][cb], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+                    }
+                    if (u + 1 < LS_ROT) {
+#pragma unroll
+                        for (int i = 0; i < 2 * NCB; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x008, 16 * NCB - PER * OPS_B, 0);
+                    } else {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 16 * NCB - PER * 8, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue(ring[slot]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    continue;
+                }
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll

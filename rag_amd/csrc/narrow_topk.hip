@@ -52,6 +52,9 @@ typedef float f4acc __attribute__((ext_vector_type(4)));
 #ifndef RAG_NARROW_DEPTH2
 #define RAG_NARROW_DEPTH2 2
 #endif
+#ifndef RAG_NARROW_NSETS2
+#define RAG_NARROW_NSETS2 4
+#endif
 constexpr int NR_WAVES = RAG_NARROW_WAVES;   // waves per workgroup (NR_WAVES / 4 per SIMD), one workgroup per CU
 constexpr int NR_TILE = 32;            // corpus rows per wave step (two 16-row MFMA row groups)
 constexpr int NR_TRIG = 32;            // compact a candidate buffer once it holds more keys than this
@@ -59,9 +62,21 @@ constexpr int NR_CAP = NR_TRIG + NR_TILE;   // 64: one key per lane when sorted
 constexpr int NR_MAX_K = 32;
 
 // timing-only ablations for diagnostic builds (outputs are wrong when non-zero): bit 0 skips the tile epilogue,
-// bit 1 loads the same bytes as 1 KiB contiguous per wave instruction (what the access pattern costs)
+// bit 1 loads the same bytes as 1 KiB contiguous per wave instruction (what the access pattern costs), bit 2 issues no row
+// loads inside the K loop (matrix cores + LDS alone), bit 3 replaces every MFMA by one multiply-add (row stream + LDS alone)
 #ifndef RAG_NARROW_DIAG
 #define RAG_NARROW_DIAG 0
+#endif
+// issue-order experiments (measurement knobs): a scheduling barrier behind every group of loads, a raised wave priority
+// around the MFMAs of a K step, LDS operations dealt between the MFMAs of a K step
+#ifndef RAG_NARROW_SCHEDBAR
+#define RAG_NARROW_SCHEDBAR 1
+#endif
+#ifndef RAG_NARROW_PRIO
+#define RAG_NARROW_PRIO 0
+#endif
+#ifndef RAG_NARROW_SGB
+#define RAG_NARROW_SGB 4
 #endif
 
 struct NarrowArgs {
@@ -179,7 +194,9 @@ __global__ __launch_bounds__(NR_WAVES * 64, NR_WAVES / 4) void narrow_topk_kerne
         for (int rg = 0; rg < 2; ++rg)
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) lp[rg][hh] = row_ptr(lt, rg, hh);
+        bool primed = false;
         auto issue = [&](AChunk (&set)[DEPTH]) {
+            if ((RAG_NARROW_DIAG & 4) && primed) return;
 #pragma unroll
             for (int j = 0; j < DEPTH; ++j)
 #pragma unroll
@@ -198,6 +215,10 @@ __global__ __launch_bounds__(NR_WAVES * 64, NR_WAVES / 4) void narrow_topk_kerne
         };
 #pragma unroll
         for (int sset = 0; sset < NSETS - 1; ++sset) issue(ring[sset]);
+        if (RAG_NARROW_DIAG & 4) {
+            issue(ring[NSETS - 1]);
+            primed = true;
+        }
         // the transposer and the query fragments run one K step ahead of the MFMAs: while a step multiplies,
         // the next step's rows go through LDS (written, then read back as fragments; one wave's LDS
         // operations complete in issue order, so the image can be reused at once)
@@ -239,7 +260,7 @@ __global__ __launch_bounds__(NR_WAVES * 64, NR_WAVES / 4) void narrow_topk_kerne
                 for (int sset = 0; sset < NSETS; ++sset) {
                     // the set that was multiplied last is free: the group NSETS - 1 ahead goes there
                     issue(ring[(sset + NSETS - 1) % NSETS]);
-                    __builtin_amdgcn_sched_barrier(0);
+                    if (RAG_NARROW_SCHEDBAR) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int j = 0; j < DEPTH; ++j) {
                         const int par = (sset * DEPTH + j) & 1;          // NSETS * DEPTH is even: the parity repeats per iteration
@@ -249,6 +270,7 @@ __global__ __launch_bounds__(NR_WAVES * 64, NR_WAVES / 4) void narrow_topk_kerne
                         if (j + 1 < DEPTH) transpose(ring[sset][j + 1], par ^ 1);
                         else transpose(ring[(sset + 1) % NSETS][0], par ^ 1);
                         read_queries(nstep, par ^ 1);
+                        if (RAG_NARROW_PRIO) __builtin_amdgcn_s_setprio(RAG_NARROW_PRIO);
 #pragma unroll
                         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -256,8 +278,81 @@ __global__ __launch_bounds__(NR_WAVES * 64, NR_WAVES / 4) void narrow_topk_kerne
 #pragma unroll
                                 for (int rg = 0; rg < 2; ++rg)
 #pragma unroll
-                                    for (int nj = 0; nj < NJ; ++nj)
-                                        acc[rg][nj] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[par][rg][m][v], bq[par][m][nj][v], acc[rg][nj], 0, 0, 0);
+                                    for (int nj = 0; nj < NJ; ++nj) {
+                                        if (RAG_NARROW_DIAG & 8) acc[rg][nj][v] += af[par][rg][m][v] * bq[par][m][nj][v];
+                                        else acc[rg][nj] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[par][rg][m][v], bq[par][m][nj][v], acc[rg][nj], 0, 0, 0);
+                                    }
+                        if (RAG_NARROW_PRIO) __builtin_amdgcn_s_setprio(0);
+                        if (RAG_NARROW_SGB == 1) {
+                            // 4 transposer writes, 4 + 2 NJ fragment reads, 16 NJ MFMAs: one LDS operation per 2 MFMAs up front
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                            }
+#pragma unroll
+                            for (int i = 0; i < 4 + 2 * NJ; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            }
+                            __builtin_amdgcn_sched_group_barrier(0x008, 16 * NJ - 8 - (4 + 2 * NJ), 0);
+                        }
+                        if (RAG_NARROW_SGB == 2) {
+                            // as 1, with the row loads of a group dealt between the first MFMAs of its first K step
+                            if (j == 0) {
+#pragma unroll
+                                for (int i = 0; i < 4 * DEPTH; ++i) {
+                                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                }
+                            }
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            }
+#pragma unroll
+                            for (int i = 0; i < 4 + 2 * NJ; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            }
+                            if (j == 0) __builtin_amdgcn_sched_group_barrier(0x008, 16 * NJ - 4 * DEPTH - 4 - (4 + 2 * NJ), 0);
+                            else __builtin_amdgcn_sched_group_barrier(0x008, 16 * NJ - 4 - (4 + 2 * NJ), 0);
+                        }
+                        if (RAG_NARROW_SGB == 3) {
+                            // query fragments first, then the transposer: writes, then reads, one LDS operation per MFMA
+#pragma unroll
+                            for (int i = 0; i < 2 * NJ; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            }
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                            }
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            }
+                            __builtin_amdgcn_sched_group_barrier(0x008, 16 * NJ - 2 * NJ - 8 - 4, 0);
+                        }
+                        if (RAG_NARROW_SGB == 4) {
+                            // as 1 with the LDS operations spread over the whole step: one per 16 NJ / (8 + 2 NJ) MFMAs
+                            constexpr int OPS = 8 + 2 * NJ, PER = 16 * NJ / OPS, REST = 16 * NJ - PER * OPS;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+                            }
+#pragma unroll
+                            for (int i = 0; i < 4 + 2 * NJ; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+                            }
+                            if (REST > 0) __builtin_amdgcn_sched_group_barrier(0x008, REST, 0);
+                        }
                     }
                 }
             }
@@ -469,7 +564,7 @@ static int launch_narrow_shape(const NarrowArgs& a, int nj, int grid, size_t lds
     // 4 register sets of 2 K steps where a row holds a multiple of 8 steps (ld % 256 == 0), of 1 step otherwise
     const bool wide = (a.ld % 256) == 0;
     if (nj == 1) return wide ? launch_narrow<1, RAG_NARROW_DEPTH1, 4>(a, grid, lds, device, s) : launch_narrow<1, 1, 4>(a, grid, lds, device, s);
-    return wide ? launch_narrow<2, RAG_NARROW_DEPTH2, 4>(a, grid, lds, device, s) : launch_narrow<2, 1, 4>(a, grid, lds, device, s);
+    return wide ? launch_narrow<2, RAG_NARROW_DEPTH2, RAG_NARROW_NSETS2>(a, grid, lds, device, s) : launch_narrow<2, 1, 4>(a, grid, lds, device, s);
 }
 
 // The score-writing variant for the segment walk: up to 32 queries against `rows` rows starting at X, every score to
