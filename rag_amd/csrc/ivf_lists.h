@@ -9,7 +9,10 @@ struct rag_index;
 
 namespace rag {
 
-constexpr int LS_GRID = 512;      // persistent workgroups (2 per compute unit)
+#ifndef RAG_LISTS_WGS_PER_CU
+#define RAG_LISTS_WGS_PER_CU 2     // measurement knob: the register budget of the kernel follows it
+#endif
+constexpr int LS_GRID = 256 * RAG_LISTS_WGS_PER_CU;      // persistent workgroups
 constexpr int LS_QT = 32;         // (query, probe) pairs per work item
 constexpr int LS_MAX_K = 32;
 

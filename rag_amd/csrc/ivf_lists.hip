@@ -337,6 +337,26 @@ __device__ __forceinline__ void ls_scan_rows(const ListScanArgs& a, f4* tp, f4* 
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
                     }
+                    if (RAG_LISTS_SGB == 2) {
+                        // the row loads of the step DEPTH ahead as well, behind the LDS operations
+                        issue(ring[slot]);
+                        if (u + 1 < LS_ROT) {
+#pragma unroll
+                            for (int i = 0; i < 2 * NCB; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        }
+                        if (u + 1 < LS_ROT) __builtin_amdgcn_sched_group_barrier(0x008, 16 * NCB - PER * OPS_B - 4, 0);
+                        else __builtin_amdgcn_sched_group_barrier(0x008, 16 * NCB - PER * 8 - 4, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        continue;
+                    }
                     if (u + 1 < LS_ROT) {
 #pragma unroll
                         for (int i = 0; i < 2 * NCB; ++i) {
@@ -392,7 +412,7 @@ __device__ __forceinline__ void ls_scan_rows(const ListScanArgs& a, f4* tp, f4* 
 }
 
 template <int DEPTH1, int DEPTH2, bool MASKED>
-__global__ __launch_bounds__(LS_WAVES * 64, 2) void ivf_lists_kernel(ListScanArgs a) {
+__global__ __launch_bounds__(LS_WAVES * 64, RAG_LISTS_WGS_PER_CU) void ivf_lists_kernel(ListScanArgs a) {
     __shared__ __attribute__((aligned(16))) f4 s_tp[LS_WAVES * 256];          // transposers, 4 KiB per wave
     __shared__ __attribute__((aligned(16))) f4 s_bq[2 * LS_ROT * 256];        // query images: two rotations of four K steps, 4 KiB each
     __shared__ float s_thr[LS_WAVES * LS_QT];
