@@ -167,6 +167,36 @@ int rag_index_search_segments_fused(rag_index_t* h, int64_t nq, const float* q, 
                                     int k, float min_score, const uint8_t* row_mask, int limit,
                                     int64_t* out_rows, double* out_scores, int32_t* out_strategy,
                                     int32_t* n_out);
+/* ---- caller filters kept on the device ---------------------------------------
+ * The reference sends the same payload filter with every search of a user
+ * (vector_db/search_manager.py:893 `{"user_id": ...}`, turned into Filter(must=...) at
+ * vector_db/search_optimizer.py:173-201 and evaluated by the server against its payload
+ * index).  A row_mask argument is copied to the device on every call -- one byte per row,
+ * 10 MB per search of a 10M-row index; a filter object holds those bytes in device memory
+ * instead, so a repeated filter costs nothing per search.
+ *   rag_filter_create   copies n bytes (1 = row may be returned) to `device`; blocking
+ *   rag_filter_free     releases them (waits for searches that still read them)
+ * A filter fits an index on the same device with exactly n rows: after rows were added the
+ * search calls below answer RAG_ERR_INVALID and the caller makes a new filter.  Filters are
+ * read-only and may be shared by threads and indexes.  rag_filter_device_bytes gives the
+ * device address for the *_device entry points' row_mask_dev arguments. */
+typedef struct rag_filter rag_filter_t;
+int rag_filter_create(int device, int64_t n, const uint8_t* row_mask, rag_filter_t** out);
+int rag_filter_free(rag_filter_t* f);
+int64_t rag_filter_rows(const rag_filter_t* f);
+const uint8_t* rag_filter_device_bytes(const rag_filter_t* f);
+/* rag_index_search / rag_index_search_segments / rag_index_search_segments_fused with the
+ * filter taken from a filter object (NULL = no filter); everything else as documented there */
+int rag_index_search_filtered(rag_index_t* h, int64_t nq, const float* q, int k, float min_score,
+                              int nprobe, const rag_filter_t* filter, float* D, int64_t* I);
+int rag_index_search_segments_filtered(rag_index_t* h, int64_t nq, const float* q, int64_t nseg,
+                                       const int64_t* seg_begin, const int64_t* seg_end, int k,
+                                       float min_score, const rag_filter_t* filter, float* D, int64_t* I);
+int rag_index_search_segments_fused_filtered(rag_index_t* h, int64_t nq, const float* q, const double* weights,
+                                             int64_t nseg, const int64_t* seg_begin, const int64_t* seg_end,
+                                             int k, float min_score, const rag_filter_t* filter, int limit,
+                                             int64_t* out_rows, double* out_scores, int32_t* out_strategy,
+                                             int32_t* n_out);
 /* which kernel path the last search on this index used: "none", "empty", "scan" (1-4 queries, HBM scan), "direct" (1-4
  * queries over <= 32768 rows), "narrow" (5-32 queries, one HBM-rate pass on the matrix cores), "gemm" (the selecting
  * matrix-core kernel), "gemm-seeded" (the same with thresholds that start from a bound taken from the leading rows: k in 65..200 on 2^20+ rows,

@@ -56,6 +56,14 @@ SIGNATURES = {
     "rag_index_search_segments": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _f32, _vp, _vp, _vp]),
     "rag_index_search_segments_fused": (_i32, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i32, _f32, _vp, _i32, _vp, _vp,
                                                _vp, _vp]),
+    "rag_filter_create": (_i32, [_i32, _i64, _vp, C.POINTER(_vp)]),
+    "rag_filter_free": (_i32, [_vp]),
+    "rag_filter_rows": (_i64, [_vp]),
+    "rag_filter_device_bytes": (_vp, [_vp]),
+    "rag_index_search_filtered": (_i32, [_vp, _i64, _vp, _i32, _f32, _i32, _vp, _vp, _vp]),
+    "rag_index_search_segments_filtered": (_i32, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _f32, _vp, _vp, _vp]),
+    "rag_index_search_segments_fused_filtered": (_i32, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i32, _f32, _vp, _i32, _vp, _vp,
+                                                        _vp, _vp]),
     "rag_index_last_path": (C.c_char_p, [_vp]),
     "rag_merge_topk_device": (_i32, [_i32, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _vp]),
     "rag_merge_topk_device_static": (_i32, [_i32, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _vp]),

@@ -713,14 +713,33 @@ int search_device_enqueue(rag_index* h, int64_t nq, const float* q_dev, int k, f
 
 extern "C" {
 
-int rag_index_search(rag_index_t* h, int64_t nq, const float* q, int k, float min_score, int nprobe,
-                     const uint8_t* row_mask, float* D, int64_t* I) {
+// A caller filter kept in device memory (rag_filter_create): one byte per row of the index it was made for.
+struct rag_filter {
+    int device;
+    long long n;
+    uint8_t* dev;
+};
+
+// the filter's bytes for a search on h, or an error when it belongs to another device or another row count
+static int filter_bytes(const rag_index* h, const rag_filter* f, const uint8_t** out) {
+    *out = nullptr;
+    if (!f) return RAG_OK;
+    if (f->device != h->device) return fail(RAG_ERR_INVALID, "the filter lives on another device than the index");
+    if (f->n != h->n) return fail(RAG_ERR_INVALID, "the filter was made for " + std::to_string(f->n) + " rows, the index holds " + std::to_string(h->n));
+    *out = f->dev;
+    return RAG_OK;
+}
+
+static int search_host(rag_index_t* h, int64_t nq, const float* q, int k, float min_score, int nprobe,
+                       const uint8_t* row_mask, const rag_filter* filter, float* D, int64_t* I) {
     if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
     if (nq < 0) return fail(RAG_ERR_INVALID, "nq < 0");
     if (k < 1 || k > 1024) return fail(RAG_ERR_INVALID, "k must be in [1, 1024]");
     if (nq == 0) return RAG_OK;
     if (!q || !D || !I) return fail(RAG_ERR_INVALID, "NULL buffer");
     RAG_LOCK_INDEX(h);
+    const uint8_t* f_dev = nullptr;
+    if (int rc = filter_bytes(h, filter, &f_dev)) return rc;
     DeviceGuard g(h->device);
     // staging in a separate allocation from the search workspaces
     Workspace& st = thread_workspace(TWS_STAGE, h->device);
@@ -733,15 +752,69 @@ int rag_index_search(rag_index_t* h, int64_t nq, const float* q, int k, float mi
     float* q_dev = reinterpret_cast<float*>(base);
     float* D_dev = reinterpret_cast<float*>(base + qb);
     int64_t* I_dev = reinterpret_cast<int64_t*>(base + qb + db);
-    uint8_t* m_dev = row_mask ? reinterpret_cast<uint8_t*>(base + qb + db + ib) : nullptr;
+    const uint8_t* m_dev = row_mask ? reinterpret_cast<uint8_t*>(base + qb + db + ib) : f_dev;
     RAG_HIP_CHECK(hipMemcpyAsync(q_dev, q, (size_t)nq * h->dim * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    if (row_mask && h->n > 0) RAG_HIP_CHECK(hipMemcpyAsync(m_dev, row_mask, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+    if (row_mask && h->n > 0)
+        RAG_HIP_CHECK(hipMemcpyAsync(base + qb + db + ib, row_mask, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
     if (int rc = rag_index_search_device(h, nq, q_dev, k, min_score, nprobe, m_dev, D_dev, I_dev, h->stream)) return rc;
     RAG_HIP_CHECK(hipMemcpyAsync(D, D_dev, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     RAG_HIP_CHECK(hipMemcpyAsync(I, I_dev, (size_t)nq * k * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
     RAG_HIP_CHECK(hipStreamSynchronize(h->stream));
     return RAG_OK;
 }
+
+int rag_index_search(rag_index_t* h, int64_t nq, const float* q, int k, float min_score, int nprobe,
+                     const uint8_t* row_mask, float* D, int64_t* I) {
+    return search_host(h, nq, q, k, min_score, nprobe, row_mask, nullptr, D, I);
+}
+
+int rag_index_search_filtered(rag_index_t* h, int64_t nq, const float* q, int k, float min_score, int nprobe,
+                              const rag_filter_t* filter, float* D, int64_t* I) {
+    return search_host(h, nq, q, k, min_score, nprobe, nullptr, filter, D, I);
+}
+
+int rag_filter_create(int device, int64_t n, const uint8_t* row_mask, rag_filter_t** out) {
+    if (!out) return fail(RAG_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (n < 0 || (n > 0 && !row_mask)) return fail(RAG_ERR_INVALID, "filter: n < 0 or NULL bytes");
+    int ndev = 0;
+    RAG_HIP_CHECK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(RAG_ERR_INVALID, "no such device");
+    DeviceGuard g(device);
+    uint8_t* dev = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&dev), (size_t)std::max<int64_t>(n, 1)) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(RAG_ERR_OOM, "out of device memory for a filter of " + std::to_string(n) + " rows");
+    }
+    // a blocking copy: the bytes are in place for any stream when this returns
+    if (n > 0) {
+        const hipError_t e = hipMemcpy(dev, row_mask, (size_t)n, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(dev);
+            return fail(RAG_ERR_HIP, std::string("filter upload: ") + hipGetErrorString(e));
+        }
+    }
+    rag_filter* f = new (std::nothrow) rag_filter{device, (long long)n, dev};
+    if (!f) {
+        (void)hipFree(dev);
+        return fail(RAG_ERR_OOM, "out of host memory");
+    }
+    *out = f;
+    return RAG_OK;
+}
+
+int rag_filter_free(rag_filter_t* f) {
+    if (!f) return RAG_OK;
+    DeviceGuard g(f->device);
+    const hipError_t e = hipFree(f->dev);        // waits for the searches that still read it
+    delete f;
+    if (e != hipSuccess) return fail(RAG_ERR_HIP, std::string("filter free: ") + hipGetErrorString(e));
+    return RAG_OK;
+}
+
+int64_t rag_filter_rows(const rag_filter_t* f) { return f ? f->n : -1; }
+
+const uint8_t* rag_filter_device_bytes(const rag_filter_t* f) { return f ? f->dev : nullptr; }
 
 // device part of a segment search: the k best of every (query, segment) pair left in h->ws2 as
 // D_dev / I_dev [nq][nseg][k] (and the row positions in R_dev when asked for); nothing synchronised.
@@ -767,7 +840,7 @@ static int segments_check(rag_index_t* h, int64_t nq, const float* q, int64_t ns
 
 static int segments_enqueue(rag_index_t* h, int64_t nq, const float* q, int64_t nseg, const int64_t* seg_begin,
                             const int64_t* seg_end, long long rows_total, int k, float min_score, const uint8_t* row_mask,
-                            bool want_rows, size_t tail, float** D_out, long long** I_out, long long** R_out, char** tail_dev,
+                            const uint8_t* row_mask_dev, bool want_rows, size_t tail, float** D_out, long long** I_out, long long** R_out, char** tail_dev,
                             hipStream_t s) {
     // effective mask
     const uint8_t* mask = nullptr;
@@ -791,6 +864,8 @@ static int segments_enqueue(rag_index_t* h, int64_t nq, const float* q, int64_t 
     if (row_mask) {
         RAG_HIP_CHECK(hipMemcpyAsync(m_user, row_mask, (size_t)h->n, hipMemcpyHostToDevice, s));
         mask = m_user;
+    } else if (row_mask_dev) {
+        mask = row_mask_dev;
     }
     if (h->active) {
         if (mask) {
@@ -855,13 +930,15 @@ static int segments_enqueue(rag_index_t* h, int64_t nq, const float* q, int64_t 
     return RAG_OK;
 }
 
-int rag_index_search_segments(rag_index_t* h, int64_t nq, const float* q, int64_t nseg, const int64_t* seg_begin,
-                              const int64_t* seg_end, int k, float min_score, const uint8_t* row_mask, float* D,
-                              int64_t* I) {
+static int search_segments_host(rag_index_t* h, int64_t nq, const float* q, int64_t nseg, const int64_t* seg_begin,
+                                const int64_t* seg_end, int k, float min_score, const uint8_t* row_mask,
+                                const rag_filter* filter, float* D, int64_t* I) {
     if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
     RAG_LOCK_INDEX(h);
     long long rows_total = 0;
     if (int rc = segments_check(h, nq, q, nseg, seg_begin, seg_end, k, &rows_total)) return rc;
+    const uint8_t* f_dev = nullptr;
+    if (int rc = filter_bytes(h, filter, &f_dev)) return rc;
     if (nq == 0 || nseg == 0) return RAG_OK;
     if (!D || !I) return fail(RAG_ERR_INVALID, "NULL buffer");
     DeviceGuard g(h->device);
@@ -869,8 +946,8 @@ int rag_index_search_segments(rag_index_t* h, int64_t nq, const float* q, int64_
     if (int rc = ws_acquire(h, s)) return rc;
     float* D_dev = nullptr;
     long long* I_dev = nullptr;
-    if (int rc = segments_enqueue(h, nq, q, nseg, seg_begin, seg_end, rows_total, k, min_score, row_mask, false, 0, &D_dev, &I_dev,
-                                  nullptr, nullptr, s))
+    if (int rc = segments_enqueue(h, nq, q, nseg, seg_begin, seg_end, rows_total, k, min_score, row_mask, f_dev, false, 0, &D_dev,
+                                  &I_dev, nullptr, nullptr, s))
         return rc;
     RAG_HIP_CHECK(hipMemcpyAsync(D, D_dev, (size_t)nq * nseg * k * sizeof(float), hipMemcpyDeviceToHost, s));
     RAG_HIP_CHECK(hipMemcpyAsync(I, I_dev, (size_t)nq * nseg * k * sizeof(long long), hipMemcpyDeviceToHost, s));
@@ -880,15 +957,29 @@ int rag_index_search_segments(rag_index_t* h, int64_t nq, const float* q, int64_
     return RAG_OK;
 }
 
+int rag_index_search_segments(rag_index_t* h, int64_t nq, const float* q, int64_t nseg, const int64_t* seg_begin,
+                              const int64_t* seg_end, int k, float min_score, const uint8_t* row_mask, float* D,
+                              int64_t* I) {
+    return search_segments_host(h, nq, q, nseg, seg_begin, seg_end, k, min_score, row_mask, nullptr, D, I);
+}
+
+int rag_index_search_segments_filtered(rag_index_t* h, int64_t nq, const float* q, int64_t nseg, const int64_t* seg_begin,
+                                       const int64_t* seg_end, int k, float min_score, const rag_filter_t* filter, float* D,
+                                       int64_t* I) {
+    return search_segments_host(h, nq, q, nseg, seg_begin, seg_end, k, min_score, nullptr, filter, D, I);
+}
+
 // vector_db/search_manager.py:877-932 on the device: see include/rag_hip.h
-int rag_index_search_segments_fused(rag_index_t* h, int64_t nq, const float* q, const double* weights, int64_t nseg,
-                                    const int64_t* seg_begin, const int64_t* seg_end, int k, float min_score,
-                                    const uint8_t* row_mask, int limit, int64_t* out_rows, double* out_scores,
-                                    int32_t* out_strategy, int32_t* n_out) {
+static int search_segments_fused_host(rag_index_t* h, int64_t nq, const float* q, const double* weights, int64_t nseg,
+                                      const int64_t* seg_begin, const int64_t* seg_end, int k, float min_score,
+                                      const uint8_t* row_mask, const rag_filter* filter, int limit, int64_t* out_rows,
+                                      double* out_scores, int32_t* out_strategy, int32_t* n_out) {
     if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
     RAG_LOCK_INDEX(h);
     long long rows_total = 0;
     if (int rc = segments_check(h, nq, q, nseg, seg_begin, seg_end, k, &rows_total)) return rc;
+    const uint8_t* f_dev = nullptr;
+    if (int rc = filter_bytes(h, filter, &f_dev)) return rc;
     if (!n_out) return fail(RAG_ERR_INVALID, "n_out is NULL");
     *n_out = 0;
     if (limit < 1 || limit > 1024) return fail(RAG_ERR_INVALID, "limit must be in [1, 1024]");
@@ -904,8 +995,8 @@ int rag_index_search_segments_fused(rag_index_t* h, int64_t nq, const float* q, 
     long long* I_dev = nullptr;
     long long* R_dev = nullptr;
     char* tail_dev = nullptr;
-    if (int rc = segments_enqueue(h, nq, q, nseg, seg_begin, seg_end, rows_total, k, min_score, row_mask, true, tail, &D_dev, &I_dev,
-                                  &R_dev, &tail_dev, s))
+    if (int rc = segments_enqueue(h, nq, q, nseg, seg_begin, seg_end, rows_total, k, min_score, row_mask, f_dev, true, tail, &D_dev,
+                                  &I_dev, &R_dev, &tail_dev, s))
         return rc;
     long long* rows_dev = nullptr;
     double* scores_dev = nullptr;
@@ -925,6 +1016,22 @@ int rag_index_search_segments_fused(rag_index_t* h, int64_t nq, const float* q, 
     if (n < 0 || n > limit) return fail(RAG_ERR_HIP, "fan-out ranking returned a bad count");
     *n_out = n;
     return RAG_OK;
+}
+
+int rag_index_search_segments_fused(rag_index_t* h, int64_t nq, const float* q, const double* weights, int64_t nseg,
+                                    const int64_t* seg_begin, const int64_t* seg_end, int k, float min_score,
+                                    const uint8_t* row_mask, int limit, int64_t* out_rows, double* out_scores,
+                                    int32_t* out_strategy, int32_t* n_out) {
+    return search_segments_fused_host(h, nq, q, weights, nseg, seg_begin, seg_end, k, min_score, row_mask, nullptr, limit, out_rows,
+                                      out_scores, out_strategy, n_out);
+}
+
+int rag_index_search_segments_fused_filtered(rag_index_t* h, int64_t nq, const float* q, const double* weights, int64_t nseg,
+                                             const int64_t* seg_begin, const int64_t* seg_end, int k, float min_score,
+                                             const rag_filter_t* filter, int limit, int64_t* out_rows, double* out_scores,
+                                             int32_t* out_strategy, int32_t* n_out) {
+    return search_segments_fused_host(h, nq, q, weights, nseg, seg_begin, seg_end, k, min_score, nullptr, filter, limit, out_rows,
+                                      out_scores, out_strategy, n_out);
 }
 
 // shared by the two merge entry points: argument checks, lists -> keys in `keys`, merge

@@ -29,6 +29,52 @@ def _ptr(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+class DeviceFilter:
+    """A payload filter resolved to one byte per row and kept in device memory (``rag_filter_*``): what the
+    reference sends with every search of a user (vector_db/search_manager.py:893) is uploaded once and passed
+    as ``row_mask`` to any search of an index with that many rows on that device."""
+
+    def __init__(self, mask, device: int = 0):
+        m = np.ascontiguousarray(mask, dtype=np.uint8).reshape(-1)
+        self.device = int(device)
+        self.n = int(m.size)
+        self._f = C.c_void_p()
+        check(lib.rag_filter_create(self.device, self.n, _ptr(m), C.byref(self._f)))
+
+    def __len__(self) -> int:
+        return self.n
+
+    @property
+    def device_ptr(self) -> int:
+        return int(lib.rag_filter_device_bytes(self._f) or 0)
+
+    def close(self) -> None:
+        if getattr(self, "_f", None) is not None and self._f.value:
+            lib.rag_filter_free(self._f)
+            self._f = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _device_mask_ptr(row_mask, index):
+    """Device address of a filter given as a DeviceFilter or a CUDA uint8 tensor (None: no filter)."""
+    if row_mask is None:
+        return None, None
+    if isinstance(row_mask, DeviceFilter):
+        if row_mask.n != len(index) or row_mask.device != index.device:
+            raise ValueError("the filter was made for another row count or device")
+        return C.c_void_p(row_mask.device_ptr), row_mask
+    import torch
+    if not _is_torch_cuda(row_mask) or row_mask.dtype != torch.uint8 or row_mask.numel() != len(index):
+        raise ValueError("row_mask must be a DeviceFilter or a CUDA uint8 tensor with one byte per row")
+    row_mask = row_mask.contiguous()
+    return C.c_void_p(row_mask.data_ptr()), row_mask
+
+
 class DeviceIndex:
     """metric: 'ip' | 'cosine' | 'l2'; kind: 'flat' | 'ivf'.
 
@@ -168,6 +214,14 @@ class DeviceIndex:
         ns = 0 if s is None else s.shape[0]
         check(lib.rag_index_train_ivf(self._h, int(nlist), _ptr(c), ns, _ptr(s)))
 
+    def make_filter(self, mask) -> DeviceFilter:
+        """``mask`` (one byte per row, 1 = may be returned) uploaded once; pass the result as ``row_mask``."""
+        f = DeviceFilter(mask, self.device)
+        if f.n != len(self):
+            f.close()
+            raise ValueError("row_mask must have one byte per row")
+        return f
+
     # -------------------------------------------------------------------- search
     def search_into(self, q, k: int, d_ptr: int, i_ptr: int, min_score: Optional[float] = None,
                     nprobe: int = 1, row_mask=None) -> None:
@@ -182,11 +236,7 @@ class DeviceIndex:
         if not 1 <= int(k) <= MAX_K:
             raise ValueError(f"k must be in [1, {MAX_K}]")
         q = q.contiguous()
-        m_ptr = None
-        if row_mask is not None:
-            if not _is_torch_cuda(row_mask) or row_mask.dtype != torch.uint8 or row_mask.numel() != len(self):
-                raise ValueError("row_mask must be a CUDA uint8 tensor with one byte per row")
-            m_ptr = C.c_void_p(row_mask.contiguous().data_ptr())
+        m_ptr, _keep = _device_mask_ptr(row_mask, self)
         ms = -FLT_MAX if min_score is None else float(min_score)
         stream = torch.cuda.current_stream(q.device).cuda_stream
         check(lib.rag_index_search_device(self._h, q.shape[0], C.c_void_p(q.data_ptr()), int(k), ms, int(nprobe),
@@ -210,6 +260,11 @@ class DeviceIndex:
         nq, ns = q.shape[0], seg.shape[0]
         D = np.full((nq, ns, k), -FLT_MAX, dtype=np.float32)
         I = np.full((nq, ns, k), -1, dtype=np.int64)
+        if isinstance(row_mask, DeviceFilter):
+            ms = -FLT_MAX if min_score is None else float(min_score)
+            check(lib.rag_index_search_segments_filtered(self._h, nq, _ptr(q), ns, _ptr(sb), _ptr(se), k, ms, row_mask._f,
+                                                         _ptr(D), _ptr(I)))
+            return D, I
         m = None
         if row_mask is not None:
             m = np.ascontiguousarray(row_mask, dtype=np.uint8).reshape(-1)
@@ -244,12 +299,17 @@ class DeviceIndex:
         scores = np.zeros(limit, dtype=np.float64)
         strategy = np.full(limit, -1, dtype=np.int32)
         n = C.c_int32(0)
+        ms = -FLT_MAX if min_score is None else float(min_score)
+        if isinstance(row_mask, DeviceFilter):
+            check(lib.rag_index_search_segments_fused_filtered(self._h, q.shape[0], _ptr(q), _ptr(w), seg.shape[0], _ptr(sb), _ptr(se),
+                                                               k, ms, row_mask._f, limit, _ptr(rows), _ptr(scores), _ptr(strategy),
+                                                               C.byref(n)))
+            return rows[:n.value], scores[:n.value], strategy[:n.value]
         m = None
         if row_mask is not None:
             m = np.ascontiguousarray(row_mask, dtype=np.uint8).reshape(-1)
             if m.size != len(self):
                 raise ValueError("row_mask must have one byte per row")
-        ms = -FLT_MAX if min_score is None else float(min_score)
         check(lib.rag_index_search_segments_fused(self._h, q.shape[0], _ptr(q), _ptr(w), seg.shape[0], _ptr(sb), _ptr(se),
                                                   k, ms, _ptr(m), limit, _ptr(rows), _ptr(scores), _ptr(strategy),
                                                   C.byref(n)))
@@ -275,12 +335,7 @@ class DeviceIndex:
             nq = q.shape[0]
             D = torch.empty((nq, k), dtype=torch.float32, device=q.device)
             I = torch.empty((nq, k), dtype=torch.int64, device=q.device)
-            m_ptr = None
-            if row_mask is not None:
-                if not _is_torch_cuda(row_mask) or row_mask.dtype != torch.uint8 or row_mask.numel() != len(self):
-                    raise ValueError("row_mask must be a CUDA uint8 tensor with one byte per row")
-                row_mask = row_mask.contiguous()
-                m_ptr = C.c_void_p(row_mask.data_ptr())
+            m_ptr, row_mask = _device_mask_ptr(row_mask, self)
             stream = torch.cuda.current_stream(q.device).cuda_stream
             check(lib.rag_index_search_device(self._h, nq, C.c_void_p(q.data_ptr()), k, ms, int(nprobe), m_ptr,
                                               C.c_void_p(D.data_ptr()), C.c_void_p(I.data_ptr()),
@@ -294,6 +349,9 @@ class DeviceIndex:
         nq = q.shape[0]
         D = np.empty((nq, k), dtype=np.float32)
         I = np.empty((nq, k), dtype=np.int64)
+        if isinstance(row_mask, DeviceFilter):
+            check(lib.rag_index_search_filtered(self._h, nq, _ptr(q), k, ms, int(nprobe), row_mask._f, _ptr(D), _ptr(I)))
+            return D, I
         m = None
         if row_mask is not None:
             m = np.ascontiguousarray(row_mask, dtype=np.uint8).reshape(-1)
@@ -451,12 +509,7 @@ def hybrid_mmr(index: "DeviceIndex", q, topn: int, bm25_rows, bm25_scores, *, fu
                 res[name] = torch.empty(fuse_limit, dtype=torch.float64, device=dev)
         for name, t in res.items():
             setattr(out, name, t.data_ptr())
-        m_ptr = None
-        if row_mask is not None:
-            if not _is_torch_cuda(row_mask) or row_mask.dtype != torch.uint8 or row_mask.numel() != len(index):
-                raise ValueError("row_mask must be a CUDA uint8 tensor with one byte per row")
-            row_mask = row_mask.contiguous()
-            m_ptr = C.c_void_p(row_mask.data_ptr())
+        m_ptr, row_mask = _device_mask_ptr(row_mask, index)
         stream = torch.cuda.current_stream(dev).cuda_stream
         check(lib.rag_index_hybrid_mmr_device(index._h, C.c_void_p(q.data_ptr()), topn, ms, int(nprobe), m_ptr, nb,
                                               C.c_void_p(bmr.data_ptr()) if nb else None,
@@ -541,12 +594,7 @@ def hybrid_mmr_batch(index: "DeviceIndex", q, topn: int, bm25_rows, bm25_scores,
     ids = torch.empty((nq, m_out), dtype=torch.int64, device=dev)
     scores = torch.zeros((nq, m_out), dtype=torch.float64, device=dev)
     n_out = torch.empty(nq, dtype=torch.int32, device=dev)
-    m_ptr = None
-    if row_mask is not None:
-        if not _is_torch_cuda(row_mask) or row_mask.dtype != torch.uint8 or row_mask.numel() != len(index):
-            raise ValueError("row_mask must be a CUDA uint8 tensor with one byte per row")
-        row_mask = row_mask.contiguous()
-        m_ptr = C.c_void_p(row_mask.data_ptr())
+    m_ptr, row_mask = _device_mask_ptr(row_mask, index)
     ms = -FLT_MAX if min_score is None else float(min_score)
     stream = torch.cuda.current_stream(dev).cuda_stream
     check(lib.rag_index_hybrid_mmr_batch_device(index._h, nq, C.c_void_p(q.data_ptr()), topn, ms, int(nprobe), m_ptr, nb,

@@ -38,6 +38,7 @@ class PooledCollections:
         self._hidden: set = set()                           # soft-deleted collections
         self._version = 0                                   # bumped by every change of rows or payloads
         self._mask_cache: Dict[Tuple[str, str], Tuple[int, np.ndarray]] = {}
+        self._device_filters: Dict[Tuple[Tuple[str, ...], str], Tuple[int, Any]] = {}   # finished masks kept on the device
         self._distinct_cache: Dict[str, Tuple[int, bool]] = {}
 
     def close(self) -> None:
@@ -140,6 +141,7 @@ class PooledCollections:
         self.index, self.payloads, self.point_ids, self.ranges, self._rows = fresh, payloads, point_ids, ranges, rows_of
         self._version += 1
         self._mask_cache.clear()
+        self._device_filters.clear()
         return dead
 
     def backup(self, path: str) -> Dict[str, Any]:
@@ -173,6 +175,7 @@ class PooledCollections:
         self._hidden = set(meta["hidden"])
         self._version = 0
         self._mask_cache = {}
+        self._device_filters = {}
         self._distinct_cache = {}
         return self
 
@@ -189,6 +192,12 @@ class PooledCollections:
         if not filters:
             return None
         fkey = repr(sorted(filters.items(), key=lambda kv: kv[0]))
+        # the finished mask of a (collections, filter) pair stays on the device until the pool changes: the same user
+        # searching the same documents again uploads nothing
+        dkey = (tuple(names), fkey)
+        dev_hit = self._device_filters.get(dkey)
+        if dev_hit is not None and dev_hit[0] == self._version:
+            return dev_hit[1]
         mask = np.zeros(len(self.payloads), dtype=np.uint8)
         for name in names:
             hit = self._mask_cache.get((name, fkey))
@@ -199,7 +208,13 @@ class PooledCollections:
                     self._mask_cache.clear()
                 self._mask_cache[(name, fkey)] = hit = (self._version, rows)
             mask[hit[1]] = 1
-        return mask
+        if mask.size != len(self.index):
+            return mask
+        if len(self._device_filters) >= 16:                  # bounded: each entry holds one byte per pool row on the device
+            self._device_filters.clear()
+        dev = self.index.make_filter(mask)
+        self._device_filters[dkey] = (self._version, dev)
+        return dev
 
     def search_many(self, names: Sequence[str], query_vectors, limit: int, min_score: Optional[float] = 0.0,
                     row_mask=None) -> List[List[List[Tuple[int, float]]]]:

@@ -96,7 +96,7 @@ class HipSearchOptimizer:
             self.index.set_active(rows, active)
 
     # ------------------------------------------------------------------ filters
-    def _mask(self, filters: Optional[Dict[str, Any]]) -> Optional[np.ndarray]:
+    def _mask(self, filters: Optional[Dict[str, Any]]):
         """search_optimizer.py:173-201: every condition must hold (Filter(must=...));
         a list value adds one equality condition per element; {'range': {...}}
         is a numeric range; anything else is equality.  One byte per row; the
@@ -110,6 +110,10 @@ class HipSearchOptimizer:
             return hit[1]
         mask = np.fromiter((payload_passes(p, filters) for p in self.payloads), dtype=np.uint8,
                            count=len(self.payloads))
+        if isinstance(self.index, DeviceIndex) and len(self.index) == mask.size:
+            # the bytes stay on the device beside the rows (the server's payload index in the reference): a
+            # repeated filter is not uploaded again
+            mask = self.index.make_filter(mask)
         if len(self._mask_cache) >= 64:
             self._mask_cache.clear()
         self._mask_cache[key] = (self._version, mask)

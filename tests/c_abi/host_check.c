@@ -103,6 +103,20 @@ int main(void) {
     CHECK(rag_index_search(h, 1, Q, k, 1.0f, 1, mask, D, I) == RAG_OK, "masked search");
     brute(X, n, d, Q, 0, n, mask, 1.0f, k, Dr, Ir);
     CHECK(same_hits(D, I, Dr, Ir, k), "masked query differs");
+    /* the same bytes kept on the device as a filter object */
+    rag_filter_t* flt = NULL;
+    CHECK(rag_filter_create(0, n, mask, &flt) == RAG_OK && flt && rag_filter_rows(flt) == n && rag_filter_device_bytes(flt),
+          "filter create");
+    CHECK(rag_index_search_filtered(h, 1, Q, k, 1.0f, 1, flt, D, I) == RAG_OK, "filtered search");
+    CHECK(same_hits(D, I, Dr, Ir, k), "filtered query differs");
+    {
+        rag_filter_t* small = NULL;
+        CHECK(rag_filter_create(0, n - 1, mask, &small) == RAG_OK, "filter create (short)");
+        CHECK(rag_index_search_filtered(h, 1, Q, k, 1.0f, 1, small, D, I) == RAG_ERR_INVALID, "filter of another row count accepted");
+        CHECK(rag_filter_free(small) == RAG_OK, "filter free (short)");
+        CHECK(rag_filter_create(0, 5, NULL, &small) == RAG_ERR_INVALID && small == NULL, "NULL filter bytes accepted");
+    }
+    CHECK(rag_filter_free(flt) == RAG_OK && rag_filter_free(NULL) == RAG_OK, "filter free");
 
     /* soft delete hides rows, restore brings them back */
     brute(X, n, d, Q, 0, n, NULL, -FLT_MAX, k, Dr, Ir);
