@@ -40,6 +40,48 @@ void Workspace::release() {
 static thread_local Workspace g_thread_ws[TWS_KINDS][64];
 Workspace& thread_workspace(int which, int device) { return g_thread_ws[which][device & 63]; }
 
+// Page-locked host memory of the calling thread for the small transfers of the host-pointer entry points (a query in, a
+// result list out): a copy from or to pageable memory is staged by the runtime and waits for it, a copy on page-locked
+// memory is one DMA command.  Grow-only, handed back by rag_thread_release().
+struct PinnedBlock {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return RAG_OK;
+        size_t want = std::max<size_t>(need, 64 * 1024);
+        want = (want + 4095) & ~(size_t)4095;
+        void* p = nullptr;
+        const hipError_t e = hipHostMalloc(&p, want, hipHostMallocPortable);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(RAG_ERR_OOM, "hipHostMalloc(" + std::to_string(want) + "): " + hipGetErrorString(e));
+        }
+        if (ptr) (void)hipHostFree(ptr);
+        ptr = p;
+        bytes = want;
+        return RAG_OK;
+    }
+    void release() {
+        if (ptr) (void)hipHostFree(ptr);
+        ptr = nullptr;
+        bytes = 0;
+    }
+};
+static thread_local PinnedBlock g_thread_pinned;
+int thread_pinned(size_t need, char** ptr) {
+    if (int rc = g_thread_pinned.ensure(need)) return rc;
+    *ptr = static_cast<char*>(g_thread_pinned.ptr);
+    return RAG_OK;
+}
+// the block for a result copy at the end of a call whose inputs may still be travelling from it: growing replaces the
+// block, so the stream is drained first (only the first calls of a thread grow it)
+static int pinned_for_results(size_t need, hipStream_t s) {
+    if (need <= g_thread_pinned.bytes) return RAG_OK;
+    RAG_HIP_CHECK(hipStreamSynchronize(s));
+    return g_thread_pinned.ensure(need);
+}
+constexpr size_t PINNED_STAGE_MAX = 4u << 20;      // larger transfers go from / to the caller's memory directly
+
 struct DeviceGuard {
     int prev = -1;
     bool ok = true;
@@ -51,6 +93,12 @@ struct DeviceGuard {
         if (prev >= 0) (void)hipSetDevice(prev);
     }
 };
+
+// a few KB between device memory and the calling thread's page-locked block (mapped into the device's address space): as a
+// kernel on the search's stream it costs a launch, not a DMA command with its own completion signalling
+__global__ void copy_words_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
 
 __global__ void fill_results_kernel(float* D, long long* I, long long n) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -186,8 +234,9 @@ size_t gemm_topk_workspace(const rag_index* h, long long nq, int k);
 bool narrow_topk_supported(const rag_index* h, long long nq, int k);          // narrow_topk.hip
 size_t narrow_topk_workspace(const rag_index* h, long long nq, int k);
 size_t fanout_workspace(long long nq, long long nseg, int k, int limit);                  // fanout.hip
-int fanout_fuse_enqueue(const float* D, const long long* R, const double* weights_host, int nq, long long nseg, int k, int limit,
-                        char* ws, long long** rows_out, double** scores_out, int** strat_out, int** n_out, hipStream_t s);
+int fanout_fuse_enqueue(const float* D, const long long* R, const double* weights_host, const double* weights_dev, int nq,
+                        long long nseg, int k, int limit, char* ws, long long** rows_out, double** scores_out, int** strat_out,
+                        int** n_out, hipStream_t s);
 bool direct_topk_supported(const rag_index* h, long long nq, int k);                      // direct_topk.hip
 size_t direct_topk_workspace(const rag_index* h, long long nq);
 int direct_topk_search(rag_index* h, long long nq, const float* qbuf, int k, float min_score, const uint8_t* mask,
@@ -344,6 +393,7 @@ int rag_thread_release(void) {
         if (hipSetDevice(dev) != hipSuccess) continue;
         for (int w = 0; w < TWS_KINDS; ++w) g_thread_ws[w][dev].release();
     }
+    g_thread_pinned.release();
     if (prev >= 0) (void)hipSetDevice(prev);
     return RAG_OK;
 }
@@ -753,10 +803,44 @@ static int search_host(rag_index_t* h, int64_t nq, const float* q, int k, float 
     float* D_dev = reinterpret_cast<float*>(base + qb);
     int64_t* I_dev = reinterpret_cast<int64_t*>(base + qb + db);
     const uint8_t* m_dev = row_mask ? reinterpret_cast<uint8_t*>(base + qb + db + ib) : f_dev;
-    RAG_HIP_CHECK(hipMemcpyAsync(q_dev, q, (size_t)nq * h->dim * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    const size_t q_bytes = (size_t)nq * h->dim * sizeof(float);
+    // small batches travel through the thread's page-locked block: the queries in one copy, scores and ids (adjacent
+    // in the staging block) back in one
+    const bool pinned = qb + db + ib <= PINNED_STAGE_MAX && g_thread_pinned.ensure(qb + db + ib) == RAG_OK;
+    char* pin = static_cast<char*>(g_thread_pinned.ptr);
+    static const int copy_kernels = env_int("RAG_STAGE_COPY_KERNELS", 1);      // measurement knob: 0 = DMA copies on the pinned block
+    const bool by_kernel = pinned && copy_kernels && qb + db + ib <= (256u << 10);
+    if (pinned) {
+        memcpy(pin, q, q_bytes);
+        if (by_kernel) {
+            const long long words = (long long)(q_bytes / 4);
+            hipLaunchKernelGGL(copy_words_kernel, dim3((unsigned)std::min<long long>(64, (words + 255) / 256)), dim3(256), 0, h->stream,
+                               reinterpret_cast<const uint32_t*>(pin), reinterpret_cast<uint32_t*>(q_dev), words);
+            RAG_HIP_CHECK(hipGetLastError());
+        } else {
+            RAG_HIP_CHECK(hipMemcpyAsync(q_dev, pin, q_bytes, hipMemcpyHostToDevice, h->stream));
+        }
+    } else {
+        RAG_HIP_CHECK(hipMemcpyAsync(q_dev, q, q_bytes, hipMemcpyHostToDevice, h->stream));
+    }
     if (row_mask && h->n > 0)
         RAG_HIP_CHECK(hipMemcpyAsync(base + qb + db + ib, row_mask, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
     if (int rc = rag_index_search_device(h, nq, q_dev, k, min_score, nprobe, m_dev, D_dev, I_dev, h->stream)) return rc;
+    if (pinned) {
+        const size_t out_bytes = db + (size_t)nq * k * sizeof(long long);
+        if (by_kernel) {
+            const long long words = (long long)(out_bytes / 4);
+            hipLaunchKernelGGL(copy_words_kernel, dim3((unsigned)std::min<long long>(64, (words + 255) / 256)), dim3(256), 0, h->stream,
+                               reinterpret_cast<const uint32_t*>(D_dev), reinterpret_cast<uint32_t*>(pin + qb), words);
+            RAG_HIP_CHECK(hipGetLastError());
+        } else {
+            RAG_HIP_CHECK(hipMemcpyAsync(pin + qb, D_dev, out_bytes, hipMemcpyDeviceToHost, h->stream));
+        }
+        RAG_HIP_CHECK(hipStreamSynchronize(h->stream));
+        memcpy(D, pin + qb, (size_t)nq * k * sizeof(float));
+        memcpy(I, pin + qb + db, (size_t)nq * k * sizeof(long long));
+        return RAG_OK;
+    }
     RAG_HIP_CHECK(hipMemcpyAsync(D, D_dev, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     RAG_HIP_CHECK(hipMemcpyAsync(I, I_dev, (size_t)nq * k * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
     RAG_HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -841,7 +925,7 @@ static int segments_check(rag_index_t* h, int64_t nq, const float* q, int64_t ns
 static int segments_enqueue(rag_index_t* h, int64_t nq, const float* q, int64_t nseg, const int64_t* seg_begin,
                             const int64_t* seg_end, long long rows_total, int k, float min_score, const uint8_t* row_mask,
                             const uint8_t* row_mask_dev, bool want_rows, size_t tail, float** D_out, long long** I_out, long long** R_out, char** tail_dev,
-                            hipStream_t s) {
+                            hipStream_t s, const double* weights = nullptr, const double** weights_dev = nullptr) {
     // effective mask
     const uint8_t* mask = nullptr;
     const size_t mb = (((size_t)h->n + 255) & ~(size_t)255);
@@ -850,17 +934,24 @@ static int segments_enqueue(rag_index_t* h, int64_t nq, const float* q, int64_t 
     const size_t ib = ((size_t)nq * nseg * k * sizeof(long long) + 255) & ~(size_t)255;
     const size_t rb = want_rows ? ib : 0;
     const size_t qhb = ((size_t)nq * h->dim * sizeof(float) + 255) & ~(size_t)255;
-    if (int rc = h->ws2.ensure(2 * mb + 2 * sb + db + ib + rb + qhb + tail)) return rc;
+    const size_t wb = weights ? (((size_t)nq * sizeof(double) + 255) & ~(size_t)255) : 0;
+    if (int rc = h->ws2.ensure(2 * mb + 2 * sb + qhb + wb + db + ib + rb + tail)) return rc;
     char* base = static_cast<char*>(h->ws2.ptr);
     uint8_t* m_user = reinterpret_cast<uint8_t*>(base);
     uint8_t* m_comb = reinterpret_cast<uint8_t*>(base + mb);
-    long long* d_sb = reinterpret_cast<long long*>(base + 2 * mb);
-    long long* d_se = reinterpret_cast<long long*>(base + 2 * mb + sb);
-    float* D_dev = reinterpret_cast<float*>(base + 2 * mb + 2 * sb);
-    long long* I_dev = reinterpret_cast<long long*>(base + 2 * mb + 2 * sb + db);
-    long long* R_dev = want_rows ? reinterpret_cast<long long*>(base + 2 * mb + 2 * sb + db + ib) : nullptr;
-    float* q_dev = reinterpret_cast<float*>(base + 2 * mb + 2 * sb + db + ib + rb);
-    if (tail_dev) *tail_dev = base + 2 * mb + 2 * sb + db + ib + rb + qhb;
+    // what the caller brings -- segment bounds, queries, weights -- sits together: one copy from the thread's page-locked block
+    char* in_dev = base + 2 * mb;
+    long long* d_sb = reinterpret_cast<long long*>(in_dev);
+    long long* d_se = reinterpret_cast<long long*>(in_dev + sb);
+    float* q_dev = reinterpret_cast<float*>(in_dev + 2 * sb);
+    double* w_dev = weights ? reinterpret_cast<double*>(in_dev + 2 * sb + qhb) : nullptr;
+    const size_t in_bytes = 2 * sb + qhb + wb;
+    char* out_base = in_dev + in_bytes;
+    float* D_dev = reinterpret_cast<float*>(out_base);
+    long long* I_dev = reinterpret_cast<long long*>(out_base + db);
+    long long* R_dev = want_rows ? reinterpret_cast<long long*>(out_base + db + ib) : nullptr;
+    if (tail_dev) *tail_dev = out_base + db + ib + rb;
+    if (weights_dev) *weights_dev = w_dev;
     if (row_mask) {
         RAG_HIP_CHECK(hipMemcpyAsync(m_user, row_mask, (size_t)h->n, hipMemcpyHostToDevice, s));
         mask = m_user;
@@ -876,9 +967,19 @@ static int segments_enqueue(rag_index_t* h, int64_t nq, const float* q, int64_t 
             mask = h->active;
         }
     }
-    RAG_HIP_CHECK(hipMemcpyAsync(d_sb, seg_begin, (size_t)nseg * sizeof(long long), hipMemcpyHostToDevice, s));
-    RAG_HIP_CHECK(hipMemcpyAsync(d_se, seg_end, (size_t)nseg * sizeof(long long), hipMemcpyHostToDevice, s));
-    RAG_HIP_CHECK(hipMemcpyAsync(q_dev, q, (size_t)nq * h->dim * sizeof(float), hipMemcpyHostToDevice, s));
+    if (in_bytes <= PINNED_STAGE_MAX && g_thread_pinned.ensure(in_bytes) == RAG_OK) {
+        char* pin = static_cast<char*>(g_thread_pinned.ptr);
+        memcpy(pin, seg_begin, (size_t)nseg * sizeof(long long));
+        memcpy(pin + sb, seg_end, (size_t)nseg * sizeof(long long));
+        memcpy(pin + 2 * sb, q, (size_t)nq * h->dim * sizeof(float));
+        if (weights) memcpy(pin + 2 * sb + qhb, weights, (size_t)nq * sizeof(double));
+        RAG_HIP_CHECK(hipMemcpyAsync(in_dev, pin, in_bytes, hipMemcpyHostToDevice, s));
+    } else {
+        RAG_HIP_CHECK(hipMemcpyAsync(d_sb, seg_begin, (size_t)nseg * sizeof(long long), hipMemcpyHostToDevice, s));
+        RAG_HIP_CHECK(hipMemcpyAsync(d_se, seg_end, (size_t)nseg * sizeof(long long), hipMemcpyHostToDevice, s));
+        RAG_HIP_CHECK(hipMemcpyAsync(q_dev, q, (size_t)nq * h->dim * sizeof(float), hipMemcpyHostToDevice, s));
+        if (weights) RAG_HIP_CHECK(hipMemcpyAsync(w_dev, weights, (size_t)nq * sizeof(double), hipMemcpyHostToDevice, s));
+    }
     // slices per segment: a slice keeps >= 8 tiles of an average segment (100 documents x 3 queries of ~225 rows x 384:
     // scan 30.8 us with one slice per pair, 20.7 us with three; 18.9 us at 4 tiles per slice, where the merge starts to grow)
     const int tile = scan_rows_per_tile(h->ld / 4);
@@ -949,9 +1050,19 @@ static int search_segments_host(rag_index_t* h, int64_t nq, const float* q, int6
     if (int rc = segments_enqueue(h, nq, q, nseg, seg_begin, seg_end, rows_total, k, min_score, row_mask, f_dev, false, 0, &D_dev,
                                   &I_dev, nullptr, nullptr, s))
         return rc;
-    RAG_HIP_CHECK(hipMemcpyAsync(D, D_dev, (size_t)nq * nseg * k * sizeof(float), hipMemcpyDeviceToHost, s));
-    RAG_HIP_CHECK(hipMemcpyAsync(I, I_dev, (size_t)nq * nseg * k * sizeof(long long), hipMemcpyDeviceToHost, s));
-    RAG_HIP_CHECK(hipStreamSynchronize(s));
+    const size_t d_bytes = (size_t)nq * nseg * k * sizeof(float), i_bytes = (size_t)nq * nseg * k * sizeof(long long);
+    const size_t i_off = reinterpret_cast<const char*>(I_dev) - reinterpret_cast<const char*>(D_dev);     // scores, padding, ids
+    if (i_off + i_bytes <= PINNED_STAGE_MAX && pinned_for_results(i_off + i_bytes, s) == RAG_OK) {
+        char* pin = static_cast<char*>(g_thread_pinned.ptr);
+        RAG_HIP_CHECK(hipMemcpyAsync(pin, D_dev, i_off + i_bytes, hipMemcpyDeviceToHost, s));
+        RAG_HIP_CHECK(hipStreamSynchronize(s));
+        memcpy(D, pin, d_bytes);
+        memcpy(I, pin + i_off, i_bytes);
+    } else {
+        RAG_HIP_CHECK(hipMemcpyAsync(D, D_dev, d_bytes, hipMemcpyDeviceToHost, s));
+        RAG_HIP_CHECK(hipMemcpyAsync(I, I_dev, i_bytes, hipMemcpyDeviceToHost, s));
+        RAG_HIP_CHECK(hipStreamSynchronize(s));
+    }
     h->ws_pending = false;
     h->last_path = "segments";
     return RAG_OK;
@@ -995,22 +1106,38 @@ static int search_segments_fused_host(rag_index_t* h, int64_t nq, const float* q
     long long* I_dev = nullptr;
     long long* R_dev = nullptr;
     char* tail_dev = nullptr;
+    const double* weights_dev = nullptr;
     if (int rc = segments_enqueue(h, nq, q, nseg, seg_begin, seg_end, rows_total, k, min_score, row_mask, f_dev, true, tail, &D_dev,
-                                  &I_dev, &R_dev, &tail_dev, s))
+                                  &I_dev, &R_dev, &tail_dev, s, weights, &weights_dev))
         return rc;
     long long* rows_dev = nullptr;
     double* scores_dev = nullptr;
     int* strat_dev = nullptr;
     int* n_dev = nullptr;
-    if (int rc = fanout_fuse_enqueue(D_dev, R_dev, weights, (int)nq, nseg, k, limit, tail_dev, &rows_dev, &scores_dev, &strat_dev,
-                                     &n_dev, s))
+    if (int rc = fanout_fuse_enqueue(D_dev, R_dev, weights, weights_dev, (int)nq, nseg, k, limit, tail_dev, &rows_dev, &scores_dev,
+                                     &strat_dev, &n_dev, s))
         return rc;
     int32_t n = 0;
-    RAG_HIP_CHECK(hipMemcpyAsync(&n, n_dev, sizeof(int), hipMemcpyDeviceToHost, s));
-    RAG_HIP_CHECK(hipMemcpyAsync(out_rows, rows_dev, (size_t)limit * sizeof(long long), hipMemcpyDeviceToHost, s));
-    RAG_HIP_CHECK(hipMemcpyAsync(out_scores, scores_dev, (size_t)limit * sizeof(double), hipMemcpyDeviceToHost, s));
-    RAG_HIP_CHECK(hipMemcpyAsync(out_strategy, strat_dev, (size_t)limit * sizeof(int), hipMemcpyDeviceToHost, s));
-    RAG_HIP_CHECK(hipStreamSynchronize(s));
+    // the four results lie in one stretch of the workspace (rows, scores, strategies, count): one copy to the page-locked block
+    const char* lo = reinterpret_cast<const char*>(rows_dev);
+    const char* hi = reinterpret_cast<const char*>(n_dev) + sizeof(int);
+    const bool one_stretch = lo < reinterpret_cast<const char*>(scores_dev) && reinterpret_cast<const char*>(scores_dev) < reinterpret_cast<const char*>(strat_dev) &&
+                             reinterpret_cast<const char*>(strat_dev) < reinterpret_cast<const char*>(n_dev) && (size_t)(hi - lo) <= PINNED_STAGE_MAX;
+    if (one_stretch && pinned_for_results((size_t)(hi - lo), s) == RAG_OK) {
+        char* pin = static_cast<char*>(g_thread_pinned.ptr);
+        RAG_HIP_CHECK(hipMemcpyAsync(pin, lo, (size_t)(hi - lo), hipMemcpyDeviceToHost, s));
+        RAG_HIP_CHECK(hipStreamSynchronize(s));
+        memcpy(&n, pin + (reinterpret_cast<const char*>(n_dev) - lo), sizeof(int));
+        memcpy(out_rows, pin, (size_t)limit * sizeof(long long));
+        memcpy(out_scores, pin + (reinterpret_cast<const char*>(scores_dev) - lo), (size_t)limit * sizeof(double));
+        memcpy(out_strategy, pin + (reinterpret_cast<const char*>(strat_dev) - lo), (size_t)limit * sizeof(int));
+    } else {
+        RAG_HIP_CHECK(hipMemcpyAsync(&n, n_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+        RAG_HIP_CHECK(hipMemcpyAsync(out_rows, rows_dev, (size_t)limit * sizeof(long long), hipMemcpyDeviceToHost, s));
+        RAG_HIP_CHECK(hipMemcpyAsync(out_scores, scores_dev, (size_t)limit * sizeof(double), hipMemcpyDeviceToHost, s));
+        RAG_HIP_CHECK(hipMemcpyAsync(out_strategy, strat_dev, (size_t)limit * sizeof(int), hipMemcpyDeviceToHost, s));
+        RAG_HIP_CHECK(hipStreamSynchronize(s));
+    }
     h->ws_pending = false;
     h->last_path = "segments-fused";
     if (n < 0 || n > limit) return fail(RAG_ERR_HIP, "fan-out ranking returned a bad count");

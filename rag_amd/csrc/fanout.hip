@@ -326,13 +326,19 @@ size_t fanout_workspace(long long nq, long long nseg, int k, int limit) {
 
 // D / R: device hit lists [nq][nseg][k]; weights_host: nq doubles; ws: fanout_workspace() bytes of
 // device memory, 256-byte aligned.  Leaves the ranked list in ws (pointers returned), nothing synchronised.
-int fanout_fuse_enqueue(const float* D, const long long* R, const double* weights_host, int nq, long long nseg, int k, int limit,
-                        char* ws, long long** rows_out, double** scores_out, int** strat_out, int** n_out, hipStream_t s) {
+// weights_dev: the weights where the caller has already brought them to the device (nullptr: copied from weights_host here)
+int fanout_fuse_enqueue(const float* D, const long long* R, const double* weights_host, const double* weights_dev, int nq,
+                        long long nseg, int k, int limit, char* ws, long long** rows_out, double** scores_out, int** strat_out,
+                        int** n_out, hipStream_t s) {
     FanoutPlan pl;
     if (!fanout_plan(nq, nseg, k, limit, &pl)) return fail(RAG_ERR_UNSUPPORTED, "fan-out fusion: shape not supported");
     if (nseg > 0x7FFFFFFFLL) return fail(RAG_ERR_INVALID, "too many segments");
-    double* weight = reinterpret_cast<double*>(ws + pl.o_weight);
-    RAG_HIP_CHECK(hipMemcpyAsync(weight, weights_host, (size_t)nq * sizeof(double), hipMemcpyHostToDevice, s));
+    const double* weight = weights_dev;
+    if (!weight) {
+        double* w = reinterpret_cast<double*>(ws + pl.o_weight);
+        RAG_HIP_CHECK(hipMemcpyAsync(w, weights_host, (size_t)nq * sizeof(double), hipMemcpyHostToDevice, s));
+        weight = w;
+    }
     FanoutArgs a = {};
     a.D = D;
     a.R = R;

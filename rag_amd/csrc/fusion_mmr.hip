@@ -837,26 +837,32 @@ static int run_fuse(int mode, int64_t n, const double* a, const double* b, const
     const size_t nb = (size_t)n * sizeof(double);
     const size_t nbp = (nb + 255) & ~(size_t)255;
     const size_t fb = ((size_t)n + 255) & ~(size_t)255;
-    // layout: a | b | out_score | out_a | out_b | has_a | has_b | order | n_out
-    const size_t total = 5 * nbp + 2 * fb + (((size_t)n * 4 + 255) & ~(size_t)255) + 256;
-    if (int rc = ws.ensure(total)) return rc;
+    // layout: inputs a | b | has_a | has_b, then results out_score | out_a | out_b | order | n_out: one copy each way
+    // through the thread's page-locked block
+    const size_t ob = ((size_t)n * 4 + 255) & ~(size_t)255;
+    const size_t in_bytes = 2 * nbp + 2 * fb, out_bytes = 3 * nbp + ob + 256;
+    if (int rc = ws.ensure(in_bytes + out_bytes)) return rc;
     char* base = static_cast<char*>(ws.ptr);
     double* da = reinterpret_cast<double*>(base);
     double* db = reinterpret_cast<double*>(base + nbp);
-    double* ds = reinterpret_cast<double*>(base + 2 * nbp);
-    double* dsa = reinterpret_cast<double*>(base + 3 * nbp);
-    double* dsb = reinterpret_cast<double*>(base + 4 * nbp);
-    uint8_t* dha = reinterpret_cast<uint8_t*>(base + 5 * nbp);
+    uint8_t* dha = reinterpret_cast<uint8_t*>(base + 2 * nbp);
     uint8_t* dhb = dha + fb;
-    int* dorder = reinterpret_cast<int*>(dhb + fb);
-    int* dnout = reinterpret_cast<int*>(reinterpret_cast<char*>(dorder) + (((size_t)n * 4 + 255) & ~(size_t)255));
+    char* out_dev = base + in_bytes;
+    double* ds = reinterpret_cast<double*>(out_dev);
+    double* dsa = reinterpret_cast<double*>(out_dev + nbp);
+    double* dsb = reinterpret_cast<double*>(out_dev + 2 * nbp);
+    int* dorder = reinterpret_cast<int*>(out_dev + 3 * nbp);
+    int* dnout = reinterpret_cast<int*>(out_dev + 3 * nbp + ob);
+    char* pin = nullptr;
+    if (int rc = thread_pinned(std::max(in_bytes, out_bytes), &pin)) return rc;
     hipStream_t s = nullptr;
-    RAG_HIP_CHECK(hipMemcpyAsync(da, a, nb, hipMemcpyHostToDevice, s));
-    RAG_HIP_CHECK(hipMemcpyAsync(db, b, nb, hipMemcpyHostToDevice, s));
+    memcpy(pin, a, nb);
+    memcpy(pin + nbp, b, nb);
     if (mode == 1) {
-        RAG_HIP_CHECK(hipMemcpyAsync(dha, has_a, (size_t)n, hipMemcpyHostToDevice, s));
-        RAG_HIP_CHECK(hipMemcpyAsync(dhb, has_b, (size_t)n, hipMemcpyHostToDevice, s));
+        memcpy(pin + 2 * nbp, has_a, (size_t)n);
+        memcpy(pin + 2 * nbp + fb, has_b, (size_t)n);
     }
+    RAG_HIP_CHECK(hipMemcpyAsync(base, pin, mode == 1 ? in_bytes : 2 * nbp, hipMemcpyHostToDevice, s));
     FuseArgs p;
     p.a = da; p.b = db; p.has_a = dha; p.has_b = dhb;
     p.wa = wa; p.wb = wb; p.max_a = max_a; p.max_b = max_b; p.threshold = thr;
@@ -867,25 +873,18 @@ static int run_fuse(int mode, int64_t n, const double* a, const double* b, const
         RAG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fuse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(fuse_kernel, dim3(1), dim3(256), lds, s, p);
     RAG_HIP_CHECK(hipGetLastError());
-    // results come back in two copies: [order | n_out] (adjacent in the workspace) and the score arrays
-    // (adjacent too); the stream is synchronised once
-    const size_t ob = ((size_t)n * 4 + 255) & ~(size_t)255;
-    std::vector<int32_t> host_order(ob / 4 + 1);
-    RAG_HIP_CHECK(hipMemcpyAsync(host_order.data(), dorder, ob + sizeof(int), hipMemcpyDeviceToHost, s));
-    if (mode == 1) {
-        std::vector<double> host_scores(3 * nbp / sizeof(double));
-        RAG_HIP_CHECK(hipMemcpyAsync(host_scores.data(), ds, 3 * nbp, hipMemcpyDeviceToHost, s));
-        RAG_HIP_CHECK(hipStreamSynchronize(s));
-        memcpy(out_score, host_scores.data(), nb);
-        memcpy(out_a, host_scores.data() + nbp / sizeof(double), nb);
-        memcpy(out_b, host_scores.data() + 2 * nbp / sizeof(double), nb);
-    } else {
-        RAG_HIP_CHECK(hipMemcpyAsync(out_score, ds, nb, hipMemcpyDeviceToHost, s));
-        RAG_HIP_CHECK(hipStreamSynchronize(s));
-    }
-    const int32_t m = host_order[ob / 4];
+    // (stream order: the input copy has left the block before the results arrive in it)
+    RAG_HIP_CHECK(hipMemcpyAsync(pin, out_dev, 3 * nbp + ob + sizeof(int), hipMemcpyDeviceToHost, s));
+    RAG_HIP_CHECK(hipStreamSynchronize(s));
+    int32_t m = 0;
+    memcpy(&m, pin + 3 * nbp + ob, sizeof(int32_t));
     if (m < 0 || (int64_t)m > n) return fail(RAG_ERR_HIP, "fusion kernel returned a bad count");
-    if (m > 0) memcpy(order, host_order.data(), (size_t)m * sizeof(int32_t));
+    memcpy(out_score, pin, nb);
+    if (mode == 1) {
+        memcpy(out_a, pin + nbp, nb);
+        memcpy(out_b, pin + 2 * nbp, nb);
+    }
+    if (m > 0) memcpy(order, pin + 3 * nbp, (size_t)m * sizeof(int32_t));
     *n_out = m;
     return RAG_OK;
 }

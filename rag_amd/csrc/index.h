@@ -38,6 +38,11 @@ struct Workspace {
 enum { TWS_STAGE = 0, TWS_MERGE = 1, TWS_FUSE = 2, TWS_KINDS = 3 };
 Workspace& thread_workspace(int which, int device);
 
+// Page-locked host memory of the calling thread (grow-only, at least `need` bytes; handed back by rag_thread_release()):
+// the small transfers of host-pointer entry points go through it as one copy each way.  A call that still has a copy
+// in flight from the block must drain its stream before asking for more.
+int thread_pinned(size_t need, char** ptr);
+
 // RAII-free helpers: record an event pair around a launch when profiling is on
 int profile_begin(rag_index* h, hipStream_t s);
 int profile_end(rag_index* h, hipStream_t s);
