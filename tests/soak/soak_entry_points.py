@@ -49,6 +49,14 @@ def segments_case(rng):
     idx = DeviceIndex(d, metric="ip")
     idx.add(X)
     D, I = idx.search_segments(Q, segs, k, min_score=min_score, row_mask=mask)
+    if mask is not None:                                                # the same bytes kept on the device as a filter object
+        flt = idx.make_filter(mask)
+        Df, If = idx.search_segments(Q, segs, k, min_score=min_score, row_mask=flt)
+        assert np.array_equal(D, Df) and np.array_equal(I, If), dict(n=n, d=d, nq=nq, k=k, what="filter object, segments")
+        Dm, Im = idx.search(Q, k, min_score=min_score, row_mask=mask)
+        Dg, Ig = idx.search(Q, k, min_score=min_score, row_mask=flt)
+        assert np.array_equal(Dm, Dg) and np.array_equal(Im, Ig), dict(n=n, d=d, nq=nq, k=k, what="filter object, search")
+        flt.close()
     for si, (b, e) in enumerate(segs):
         Dr, Ir = flat.flat_ip_search(X[b:e], Q, k, min_score=min_score, row_mask=None if mask is None else mask[b:e])
         Ir = np.where(Ir >= 0, Ir + b, -1)
