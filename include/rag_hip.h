@@ -315,6 +315,13 @@ int rag_multi_set_active(rag_multi_t* h, int64_t n, const int64_t* rows, int act
 int rag_multi_reconstruct(rag_multi_t* h, int64_t n, const int64_t* rows, float* out);
 int rag_multi_search(rag_multi_t* h, int64_t nq, const float* q, int k, float min_score, int nprobe,
                      const uint8_t* row_mask, float* D, int64_t* I);
+/* A caller filter for a several-GPU index (see rag_filter_create): ntotal bytes in insertion order, cut into the
+ * shards' own row orders and kept on each shard's device.  Fits the index until rows are added. */
+typedef struct rag_multi_filter rag_multi_filter_t;
+int rag_multi_filter_create(rag_multi_t* h, const uint8_t* row_mask, rag_multi_filter_t** out);
+int rag_multi_filter_free(rag_multi_filter_t* f);
+int rag_multi_search_filtered(rag_multi_t* h, int64_t nq, const float* q, int k, float min_score, int nprobe,
+                              const rag_multi_filter_t* filter, float* D, int64_t* I);
 /* where the last rag_multi_search merged the devices' lists: "device", "host" or "none" */
 const char* rag_multi_last_merge(const rag_multi_t* h);
 

@@ -92,6 +92,9 @@ SIGNATURES = {
     "rag_multi_set_active": (_i32, [_vp, _i64, _vp, _i32]),
     "rag_multi_reconstruct": (_i32, [_vp, _i64, _vp, _vp]),
     "rag_multi_search": (_i32, [_vp, _i64, _vp, _i32, _f32, _i32, _vp, _vp, _vp]),
+    "rag_multi_filter_create": (_i32, [_vp, _vp, C.POINTER(_vp)]),
+    "rag_multi_filter_free": (_i32, [_vp]),
+    "rag_multi_search_filtered": (_i32, [_vp, _i64, _vp, _i32, _f32, _i32, _vp, _vp, _vp]),
     "rag_multi_last_merge": (C.c_char_p, [_vp]),
     "rag_bm25_create": (_i32, [_i32, C.POINTER(_vp)]),
     "rag_bm25_destroy": (None, [_vp]),

@@ -373,8 +373,16 @@ int rag_multi_reconstruct(rag_multi_t* h, int64_t n, const int64_t* rows, float*
     return RAG_OK;
 }
 
-int rag_multi_search(rag_multi_t* h, int64_t nq, const float* q, int k, float min_score, int nprobe,
-                     const uint8_t* row_mask, float* D, int64_t* I) {
+}  // extern "C"
+
+// a caller filter cut into the shards' own row orders, each part kept on its shard's device
+struct rag_multi_filter {
+    long long n = 0;
+    std::vector<rag_filter_t*> part;
+};
+
+static int multi_search(rag_multi_t* h, int64_t nq, const float* q, int k, float min_score, int nprobe,
+                        const uint8_t* row_mask, const rag_multi_filter* filter, float* D, int64_t* I) {
     if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
     if (nq < 0 || k < 1) return fail(RAG_ERR_INVALID, "nq < 0 or k < 1");
     if (nq == 0) return RAG_OK;
@@ -382,6 +390,12 @@ int rag_multi_search(rag_multi_t* h, int64_t nq, const float* q, int k, float mi
     std::lock_guard<std::mutex> lk(h->mu);
     if (h->broken) return fail(RAG_ERR_INVALID, "a failed add left this index inconsistent: free it");
     const size_t S = h->shard.size();
+    if (filter) {
+        if (filter->n != h->n || filter->part.size() != S)
+            return fail(RAG_ERR_INVALID, "the filter was made for " + std::to_string(filter->n) + " rows, the index holds " + std::to_string(h->n));
+        for (size_t s = 0; s < S; ++s)
+            if (rag_filter_rows(filter->part[s]) != h->rows[s]) return fail(RAG_ERR_INVALID, "the filter does not fit the shards of this index");
+    }
     // the caller's mask counts rows in insertion order: cut it into the shards' own orders
     std::vector<std::vector<uint8_t>> mask(S);
     if (row_mask) {
@@ -417,10 +431,11 @@ int rag_multi_search(rag_multi_t* h, int64_t nq, const float* q, int k, float mi
             float* q_dev = reinterpret_cast<float*>(w);
             float* D_dev = reinterpret_cast<float*>(w + qb);
             int64_t* I_dev = reinterpret_cast<int64_t*>(w + qb + db);
-            uint8_t* m_dev = row_mask ? reinterpret_cast<uint8_t*>(w + qb + db + ib) : nullptr;
+            const uint8_t* m_dev = row_mask ? reinterpret_cast<uint8_t*>(w + qb + db + ib)
+                                            : filter ? rag_filter_device_bytes(filter->part[(size_t)s]) : nullptr;
             RAG_HIP_CHECK(hipMemcpyAsync(q_dev, q, (size_t)nq * h->dim * sizeof(float), hipMemcpyHostToDevice, st.stream));
             if (row_mask && h->rows[(size_t)s] > 0)
-                RAG_HIP_CHECK(hipMemcpyAsync(m_dev, mask[(size_t)s].data(), (size_t)h->rows[(size_t)s], hipMemcpyHostToDevice, st.stream));
+                RAG_HIP_CHECK(hipMemcpyAsync(w + qb + db + ib, mask[(size_t)s].data(), (size_t)h->rows[(size_t)s], hipMemcpyHostToDevice, st.stream));
             // (a shard without rows answers with empty lists by itself)
             if (int r = rag_index_search_device(h->shard[(size_t)s], nq, q_dev, k, min_score, nprobe, m_dev, D_dev, I_dev, st.stream)) return r;
             float* dst_d = reinterpret_cast<float*>(reinterpret_cast<char*>(gD) + (size_t)s * db);
@@ -459,6 +474,7 @@ int rag_multi_search(rag_multi_t* h, int64_t nq, const float* q, int k, float mi
             std::fill(i, i + per, (int64_t)-1);
             return (int)RAG_OK;
         }
+        if (filter) return rag_index_search_filtered(h->shard[(size_t)s], nq, q, k, min_score, nprobe, filter->part[(size_t)s], d, i);
         return rag_index_search(h->shard[(size_t)s], nq, q, k, min_score, nprobe, row_mask ? mask[(size_t)s].data() : nullptr, d, i);
     });
     if (rc != RAG_OK) return rc;
@@ -486,6 +502,57 @@ int rag_multi_search(rag_multi_t* h, int64_t nq, const float* q, int k, float mi
             ++head[(size_t)best];
         }
     }
+    return RAG_OK;
+}
+
+extern "C" {
+
+int rag_multi_search(rag_multi_t* h, int64_t nq, const float* q, int k, float min_score, int nprobe,
+                     const uint8_t* row_mask, float* D, int64_t* I) {
+    return multi_search(h, nq, q, k, min_score, nprobe, row_mask, nullptr, D, I);
+}
+
+int rag_multi_search_filtered(rag_multi_t* h, int64_t nq, const float* q, int k, float min_score, int nprobe,
+                              const rag_multi_filter_t* filter, float* D, int64_t* I) {
+    return multi_search(h, nq, q, k, min_score, nprobe, nullptr, filter, D, I);
+}
+
+int rag_multi_filter_free(rag_multi_filter_t* f) {
+    if (!f) return RAG_OK;
+    int rc = RAG_OK;
+    for (rag_filter_t* p : f->part) {
+        const int r = rag_filter_free(p);
+        if (r != RAG_OK) rc = r;
+    }
+    delete f;
+    return rc;
+}
+
+int rag_multi_filter_create(rag_multi_t* h, const uint8_t* row_mask, rag_multi_filter_t** out) {
+    if (!out) return fail(RAG_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (h->n > 0 && !row_mask) return fail(RAG_ERR_INVALID, "filter: NULL bytes");
+    const size_t S = h->shard.size();
+    std::unique_ptr<rag_multi_filter> f(new (std::nothrow) rag_multi_filter);
+    if (!f) return fail(RAG_ERR_OOM, "out of host memory");
+    f->n = h->n;
+    // the caller's bytes count rows in insertion order: cut them into the shards' own orders
+    std::vector<std::vector<uint8_t>> mask(S);
+    for (size_t s = 0; s < S; ++s) mask[s].resize((size_t)h->rows[s]);
+    for (const Piece& p : h->pieces) memcpy(mask[(size_t)p.shard].data() + p.local, row_mask + p.global, (size_t)p.count);
+    for (size_t s = 0; s < S; ++s) {
+        rag_filter_t* part = nullptr;
+        const int rc = rag_filter_create(h->device[s], h->rows[s], mask[s].data(), &part);
+        if (rc != RAG_OK) {
+            const std::string msg = rag_last_error();
+            (void)rag_multi_filter_free(f.release());
+            return fail(rc, msg);
+        }
+        f->part.push_back(part);
+    }
+    *out = f.release();
     return RAG_OK;
 }
 

@@ -364,6 +364,29 @@ class DeviceIndex:
 _MMR_METRICS = {"cosine": _lib.MMR_COSINE, "dot_product": _lib.MMR_DOT, "euclidean": _lib.MMR_EUCLIDEAN}
 
 
+class MultiDeviceFilter:
+    """A caller filter of a ``MultiDeviceIndex`` kept on its devices (``rag_multi_filter_*``)."""
+
+    def __init__(self, index: "MultiDeviceIndex", mask: np.ndarray):
+        self.n = int(mask.size)
+        self._f = C.c_void_p()
+        check(lib.rag_multi_filter_create(index._h, _ptr(mask), C.byref(self._f)))
+
+    def __len__(self) -> int:
+        return self.n
+
+    def close(self) -> None:
+        if getattr(self, "_f", None) is not None and self._f.value:
+            lib.rag_multi_filter_free(self._f)
+            self._f = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class MultiDeviceIndex:
     """One index over several GPUs of this process (``rag_multi_*``): rows of every ``add`` are
     dealt over the devices, a search runs on all of them at once and the answers are merged.
@@ -445,16 +468,27 @@ class MultiDeviceIndex:
             q = q[None, :]
         if q.ndim != 2 or q.shape[1] != self.dim:
             raise ValueError(f"expected float32 [nq, {self.dim}] array, got {q.shape}")
+        D = np.full((q.shape[0], k), -FLT_MAX, dtype=np.float32)
+        I = np.full((q.shape[0], k), -1, dtype=np.int64)
+        ms = -FLT_MAX if min_score is None else float(min_score)
+        if isinstance(row_mask, MultiDeviceFilter):
+            check(lib.rag_multi_search_filtered(self._h, q.shape[0], _ptr(q), k, ms, int(nprobe), row_mask._f, _ptr(D), _ptr(I)))
+            return D, I
         m = None
         if row_mask is not None:
             m = np.ascontiguousarray(row_mask, dtype=np.uint8).reshape(-1)
             if m.size != len(self):
                 raise ValueError("row_mask must have one byte per row")
-        D = np.full((q.shape[0], k), -FLT_MAX, dtype=np.float32)
-        I = np.full((q.shape[0], k), -1, dtype=np.int64)
-        ms = -FLT_MAX if min_score is None else float(min_score)
         check(lib.rag_multi_search(self._h, q.shape[0], _ptr(q), k, ms, int(nprobe), _ptr(m), _ptr(D), _ptr(I)))
         return D, I
+
+    def make_filter(self, mask) -> "MultiDeviceFilter":
+        """``mask`` (one byte per row in insertion order) cut into the shards' row orders and uploaded to
+        their devices once; pass the result as ``row_mask``."""
+        m = np.ascontiguousarray(mask, dtype=np.uint8).reshape(-1)
+        if m.size != len(self):
+            raise ValueError("row_mask must have one byte per row")
+        return MultiDeviceFilter(self, m)
 
     def hybrid_mmr(self, q, topn: int, bm25_rows, bm25_scores, **kw):
         """Search over every device -> hybrid fusion with the keyword hits (global row positions) -> MMR

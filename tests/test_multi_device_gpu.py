@@ -45,14 +45,25 @@ def test_multi_device_flat_equals_oracle_and_single_index(shards, n, d, nq, k):
     Ds, Is = single.search(Q, k, min_score=0.05, row_mask=mask)
     assert flat.compare_topk(D, I, Ds, Is, rtol=RTOL, atol=ATOL) == []
     assert not np.isin(np.flatnonzero(mask == 0), I).any()
+    # the same bytes as a filter object: cut into the shards' orders once, kept on their devices
+    flt = multi.make_filter(mask)
+    Df, If = multi.search(Q, k, min_score=0.05, row_mask=flt)
+    assert np.array_equal(Df, D) and np.array_equal(If, I)
     hide = np.unique(I[I >= 0])[:20]
     multi.set_active(hide, False)
     single.set_active(hide, False)
     D, I = multi.search(Q, k, row_mask=mask)
     Ds, Is = single.search(Q, k, row_mask=mask)
     assert flat.compare_topk(D, I, Ds, Is, rtol=RTOL, atol=ATOL) == [] and not np.isin(hide, I).any()
+    Df, If = multi.search(Q, k, row_mask=flt)               # soft deletes apply on top of a filter object as well
+    assert np.array_equal(Df, D) and np.array_equal(If, I)
     rows = rng.integers(0, n, 64)
     assert np.array_equal(multi.reconstruct(rows), X[rows])
+    multi.add(X[:3])                                         # the index grew: the filter no longer fits
+    from rag_amd import RagHipError
+    with pytest.raises(RagHipError):
+        multi.search(Q, k, row_mask=flt)
+    flt.close()
     multi.close()
     single.close()
 
