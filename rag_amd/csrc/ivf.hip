@@ -220,16 +220,23 @@ static int ivf_repack(rag_index* h) {
             v.pos[(size_t)o] = p;
         }
     }
+    // (a table that fails to grow is left empty, never pointing at freed memory)
     if (v.orig_cap < n) {
         if (v.orig_dev) (void)hipFree(v.orig_dev);
-        v.orig_cap = std::max(n, v.orig_cap + v.orig_cap / 2);
-        RAG_HIP_CHECK(hipMalloc((void**)&v.orig_dev, (size_t)v.orig_cap * sizeof(long long)));
+        v.orig_dev = nullptr;
+        const long long cap = std::max(n, v.orig_cap + v.orig_cap / 2);
+        v.orig_cap = 0;
+        RAG_HIP_CHECK(hipMalloc((void**)&v.orig_dev, (size_t)cap * sizeof(long long)));
+        v.orig_cap = cap;
     }
     RAG_HIP_CHECK(hipMemcpy(v.orig_dev, v.orig.data(), (size_t)n * sizeof(long long), hipMemcpyHostToDevice));
     if (v.pos_cap < n) {
         if (v.pos_dev) (void)hipFree(v.pos_dev);
-        v.pos_cap = std::max(n, v.pos_cap + v.pos_cap / 2);
-        RAG_HIP_CHECK(hipMalloc((void**)&v.pos_dev, (size_t)v.pos_cap * sizeof(long long)));
+        v.pos_dev = nullptr;
+        const long long cap = std::max(n, v.pos_cap + v.pos_cap / 2);
+        v.pos_cap = 0;
+        RAG_HIP_CHECK(hipMalloc((void**)&v.pos_dev, (size_t)cap * sizeof(long long)));
+        v.pos_cap = cap;
     }
     RAG_HIP_CHECK(hipMemcpy(v.pos_dev, v.pos.data(), (size_t)n * sizeof(long long), hipMemcpyHostToDevice));
     RAG_HIP_CHECK(hipMemcpy(v.list_begin_dev, begin.data(), ((size_t)v.nlist + 1) * sizeof(long long), hipMemcpyHostToDevice));
