@@ -117,6 +117,34 @@ def test_halves_merge_to_whole(corpus):
     assert np.array_equal(np.take_along_axis(both_I, order, 1), Iw.cpu().numpy())
 
 
+def test_filter_object_at_full_size(corpus):
+    """A 10 MB caller filter kept on the device: scan, narrow and GEMM paths answer what they answer with the
+    same bytes passed as a CUDA tensor, never return a filtered row, and agree with an fp64 re-score."""
+    torch, X, Q, idx, planted = corpus
+    g = torch.Generator(device=X.device)
+    g.manual_seed(21)
+    keep = (torch.rand((N,), generator=g, device=X.device) < 0.5).to(torch.uint8)
+    keep[torch.from_numpy(planted[:8]).to(X.device)] = 0          # the planted copies of queries 0..7 are filtered out
+    keep[torch.from_numpy(planted[8:]).to(X.device)] = 1          # the others may be returned
+    flt = idx.make_filter(keep.cpu().numpy())
+    for nq, path in ((1, "scan"), (16, "narrow"), (64, "gemm")):
+        Dt, It = idx.search(Q[:nq], K, row_mask=keep)
+        assert idx.last_path == path
+        Df, If = idx.search(Q[:nq], K, row_mask=flt)
+        assert idx.last_path == path
+        assert torch.equal(It, If) and torch.equal(Dt, Df)
+        assert bool(keep[If.reshape(-1)].all())
+        for qi in range(min(nq, 8)):
+            assert int(If[qi, 0]) != planted[qi]
+        if nq > 8:
+            assert np.array_equal(If[8:, 0].cpu().numpy(), planted[8:nq])
+        assert np.allclose(Df.cpu().numpy(), _rescore(torch, X, Q[:nq], If.cpu()), rtol=1e-5, atol=1e-6)
+    Dh, Ih = idx.search(Q[:2].cpu().numpy(), K, row_mask=flt)      # host arrays in and out, the filter stays where it is
+    Dd, Id = idx.search(Q[:2], K, row_mask=flt)
+    assert np.array_equal(Ih, Id.cpu().numpy()) and np.array_equal(Dh, Dd.cpu().numpy())
+    flt.close()
+
+
 def test_every_gemm_shape_agrees_with_the_scan(corpus):
     """The narrow kernel (12, 32 queries) and the tile shapes of the GEMM kernel (64, 200 and 1100
     queries) against single-query scans of the same index: identical ids, scores within tolerance."""
