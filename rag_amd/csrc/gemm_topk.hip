@@ -96,7 +96,8 @@ __host__ __device__ constexpr int gemm_capq(int RT, int QT) { return gemm_trig_m
 
 // Timing-only ablations for diagnostic builds (outputs are wrong when non-zero):
 // bit 0 skip the tile epilogue, bit 1 load global tiles only once, bit 2 barrier only twice,
-// bit 10 every load re-reads the first K step of the first tile (load issue cost without memory latency).
+// bit 10 every load re-reads the first K step of the first tile (load issue cost without memory latency),
+// bit 11 the bf16 pass issues 16x16x32 MFMAs on its fragments (same cycles; the clock the smaller shape holds).
 #ifndef RAG_GEMM_DIAG
 #define RAG_GEMM_DIAG 0
 #endif
@@ -532,8 +533,25 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_topk_kernel(Gem
                     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                         for (int nj = 0; nj < NJ; ++nj)
-                            acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, fa[cur][mi]),
-                                                                                  __builtin_bit_cast(bf8, fb[cur][nj]), acc[mi][nj], 0, 0, 0);
+                        {
+                            if (DIAG & 2048) {
+                                // timing only (answers invalid): the same fragments and cycles as 16x16x32 MFMAs, two per pair and
+                                // k block on alternating quarters of the accumulator -- does the smaller shape hold a higher clock?
+                                typedef float f4v __attribute__((ext_vector_type(4)));
+                                f16v& c = acc[mi][nj];
+#pragma unroll
+                                for (int h2 = 0; h2 < 2; ++h2) {
+                                    const int qd = 2 * (kb & 1) + h2;
+                                    f4v part = {c[4 * qd], c[4 * qd + 1], c[4 * qd + 2], c[4 * qd + 3]};
+                                    part = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, fa[cur][mi]),
+                                                                                   __builtin_bit_cast(bf8, fb[cur][nj]), part, 0, 0, 0);
+                                    c[4 * qd] = part[0]; c[4 * qd + 1] = part[1]; c[4 * qd + 2] = part[2]; c[4 * qd + 3] = part[3];
+                                }
+                            } else {
+                                acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, fa[cur][mi]),
+                                                                                      __builtin_bit_cast(bf8, fb[cur][nj]), acc[mi][nj], 0, 0, 0);
+                            }
+                        }
                 } else {
 #pragma unroll
                     for (int s = 0; s < 4; ++s)
