@@ -87,16 +87,36 @@ extern "C" int rag_index_save(rag_index_t* h, const char* path) {
             if (fwrite(host.data(), sizeof(float), (size_t)c * h->dim, f) != (size_t)c * h->dim) return fail(RAG_ERR_INVALID, "write failed");
         }
     } else {
-        // rows, 64 MiB at a time, padding stripped
-        std::vector<float> host((size_t)std::min<long long>(chunk, std::max<long long>(h->n, 1)) * h->ld);
-        for (long long r0 = 0; r0 < h->n; r0 += chunk) {
+        // rows, 64 MiB at a time, padding stripped: two page-locked buffers, so that one chunk travels from the device while the
+        // chunk before it is written to the file
+        const size_t chunk_bytes = (size_t)std::min<long long>(chunk, std::max<long long>(h->n, 1)) * h->ld * sizeof(float);
+        struct Pinned {
+            float* p[2] = {nullptr, nullptr};
+            hipStream_t s = nullptr;
+            ~Pinned() {
+                if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+                for (float* q : p) if (q) (void)hipHostFree(q);
+            }
+        } pin;
+        for (int b = 0; b < 2; ++b) RAG_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&pin.p[b]), chunk_bytes, hipHostMallocDefault));
+        RAG_HIP_CHECK(hipStreamCreateWithFlags(&pin.s, hipStreamNonBlocking));
+        RAG_HIP_CHECK(hipDeviceSynchronize());          // the rows as every stream has left them
+        auto fetch = [&](long long r0, int b) -> hipError_t {
             const long long c = std::min(chunk, h->n - r0);
-            RAG_HIP_CHECK(hipMemcpy(host.data(), h->X + (size_t)r0 * h->ld, (size_t)c * h->ld * sizeof(float), hipMemcpyDeviceToHost));
+            return hipMemcpyAsync(pin.p[b], h->X + (size_t)r0 * h->ld, (size_t)c * h->ld * sizeof(float), hipMemcpyDeviceToHost, pin.s);
+        };
+        if (h->n > 0) RAG_HIP_CHECK(fetch(0, 0));
+        int b = 0;
+        for (long long r0 = 0; r0 < h->n; r0 += chunk, b ^= 1) {
+            const long long c = std::min(chunk, h->n - r0);
+            RAG_HIP_CHECK(hipStreamSynchronize(pin.s));                    // chunk r0 is in pin.p[b]
+            if (r0 + chunk < h->n) RAG_HIP_CHECK(fetch(r0 + chunk, b ^ 1));
+            const float* host = pin.p[b];
             if (h->ld == h->dim) {
-                if (fwrite(host.data(), sizeof(float), (size_t)c * h->dim, f) != (size_t)c * h->dim) return fail(RAG_ERR_INVALID, "write failed");
+                if (fwrite(host, sizeof(float), (size_t)c * h->dim, f) != (size_t)c * h->dim) return fail(RAG_ERR_INVALID, "write failed");
             } else {
                 for (long long r = 0; r < c; ++r)
-                    if (fwrite(host.data() + (size_t)r * h->ld, sizeof(float), (size_t)h->dim, f) != (size_t)h->dim) return fail(RAG_ERR_INVALID, "write failed");
+                    if (fwrite(host + (size_t)r * h->ld, sizeof(float), (size_t)h->dim, f) != (size_t)h->dim) return fail(RAG_ERR_INVALID, "write failed");
             }
         }
     }
