@@ -197,6 +197,14 @@ int rag_index_search_segments_fused_filtered(rag_index_t* h, int64_t nq, const f
                                              int k, float min_score, const rag_filter_t* filter, int limit,
                                              int64_t* out_rows, double* out_scores, int32_t* out_strategy,
                                              int32_t* n_out);
+/* Searches of one index share its workspaces: a search on another stream than the one before it waits for that
+ * one's end.  By default every *_device search marks its end with an event (a marker packet: 2.4-3 us between two
+ * searches on the device).  streams_outlive_searches = 1 is the caller's promise that a stream handed to a search
+ * of this index is not destroyed before the NEXT search of the index has been issued (or the index freed); the end
+ * of a search is then marked only when a search on another stream needs it, and never between searches that follow
+ * each other on one stream.  The host-pointer entry points run on the index's own stream and always work that way.
+ * No counterpart in the reference (its searches are blocking RPCs). */
+int rag_index_set_stream_lifetime(rag_index_t* h, int streams_outlive_searches);
 /* which kernel path the last search on this index used: "none", "empty", "scan" (1-4 queries, HBM scan), "direct" (1-4
  * queries over <= 32768 rows), "narrow" (5-32 queries, one HBM-rate pass on the matrix cores), "gemm" (the selecting
  * matrix-core kernel), "gemm-seeded" (the same with thresholds that start from a bound taken from the leading rows: k in 65..200 on 2^20+ rows,

@@ -43,6 +43,7 @@ SIGNATURES = {
     "rag_index_adopt_device": (_i32, [_vp, _i64, _vp]),
     "rag_index_set_id_base": (_i32, [_vp, _i64]),
     "rag_index_set_prefilter": (_i32, [_vp, _i32]),
+    "rag_index_set_stream_lifetime": (_i32, [_vp, _i32]),
     "rag_index_ntotal": (_i64, [_vp]),
     "rag_index_dim": (_i32, [_vp]),
     "rag_index_metric": (_i32, [_vp]),

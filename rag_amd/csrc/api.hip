@@ -121,13 +121,30 @@ __global__ void iota_ids_kernel(long long* ids, long long begin, long long end, 
         ids[i] = base + i;
 }
 
+// The event that marks the end of a search costs a marker packet on the device (2.4-3 us between two searches).  It is only
+// needed when the NEXT search arrives on another stream, so where the stream is known to be there at that time -- the
+// index's own stream, or any stream once the caller has promised so (rag_index_set_stream_lifetime) -- it is recorded
+// then, on the old stream's present end (which lies behind that search's last launch), and not at all between searches
+// that follow each other on one stream.
 int ws_acquire(rag_index* h, hipStream_t s) {
     if (!h->ws_event) RAG_HIP_CHECK(hipEventCreateWithFlags(&h->ws_event, hipEventDisableTiming));
-    if (h->ws_pending && h->ws_stream != s) RAG_HIP_CHECK(hipStreamWaitEvent(s, h->ws_event, 0));
+    if (h->ws_pending && h->ws_stream != s) {
+        if (h->ws_unmarked) {
+            RAG_HIP_CHECK(hipEventRecord(h->ws_event, h->ws_stream));
+            h->ws_unmarked = false;
+        }
+        RAG_HIP_CHECK(hipStreamWaitEvent(s, h->ws_event, 0));
+    }
     return RAG_OK;
 }
 int ws_release(rag_index* h, hipStream_t s) {
-    RAG_HIP_CHECK(hipEventRecord(h->ws_event, s));
+    static const int eager = getenv("RAG_WS_EAGER_EVENTS") ? atoi(getenv("RAG_WS_EAGER_EVENTS")) : 0;      // measurement knob
+    if (!eager && (s == h->stream || h->streams_outlive)) {
+        h->ws_unmarked = true;
+    } else {
+        RAG_HIP_CHECK(hipEventRecord(h->ws_event, s));
+        h->ws_unmarked = false;
+    }
     h->ws_stream = s;
     h->ws_pending = true;
     return RAG_OK;
@@ -563,6 +580,13 @@ int rag_index_profile_read(rag_index_t* h, double* kernel_ms, int64_t* launches,
     *kernel_ms = total;
     *launches = (int64_t)(h->prof_used / 2);
     if (reset) h->prof_used = 0;
+    return RAG_OK;
+}
+
+int rag_index_set_stream_lifetime(rag_index_t* h, int streams_outlive_searches) {
+    if (!h) return fail(RAG_ERR_INVALID, "index is NULL");
+    RAG_LOCK_INDEX(h);
+    h->streams_outlive = streams_outlive_searches != 0;
     return RAG_OK;
 }
 

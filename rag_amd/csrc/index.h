@@ -110,6 +110,8 @@ struct rag_index {
     hipEvent_t ws_event = nullptr;  // end of the last work that used ws / ws2
     hipStream_t ws_stream = nullptr;
     bool ws_pending = false;
+    bool ws_unmarked = false;       // the last search's end has no event yet: ws_stream is marked when another stream asks
+    bool streams_outlive = false;   // the caller's promise that a search's stream is still there when the next search comes
     const char* last_path = "none";
     rag::IvfState ivf;
     // measurement: event pairs around the dominant kernel of each search

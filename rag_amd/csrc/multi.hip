@@ -226,6 +226,7 @@ int rag_multi_create(int dim, int metric, int kind, int n_devices, const int* de
             for (rag_index_t* made : h->shard) rag_index_free(made);
             return rc;
         }
+        (void)rag_index_set_stream_lifetime(idx, 1);       // a shard is searched on its stage stream, which lives as long as the shard
         h->shard.push_back(idx);
         h->device.push_back(device_ids[s]);
         h->rows.push_back(0);

@@ -96,6 +96,8 @@ class DeviceIndex:
         self._h = C.c_void_p()
         self._keepalive = None
         check(lib.rag_index_create(self.dim, metrics[metric], kinds[kind], self.device, C.byref(self._h)))
+        # searches run on torch's current stream, and torch keeps its streams for the life of the process
+        check(lib.rag_index_set_stream_lifetime(self._h, 1))
 
     # ------------------------------------------------------------------ lifetime
     def close(self) -> None:
@@ -132,6 +134,7 @@ class DeviceIndex:
         self = cls.__new__(cls)
         self._h = h
         self._keepalive = None
+        check(lib.rag_index_set_stream_lifetime(h, 1))
         self.dim = int(lib.rag_index_dim(h))
         self.device = int(device)
         self.kind = "ivf" if int(lib.rag_index_kind(h)) == _lib.KIND_IVF else "flat"

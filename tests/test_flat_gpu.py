@@ -237,6 +237,34 @@ def test_searches_on_different_streams_are_ordered():
     idx.close()
 
 
+def test_searches_alternating_between_streams_many_times():
+    """The end of a search is marked only when a search on another stream needs it (torch's streams live on, which
+    DeviceIndex tells the library): two side streams and torch's own take turns on one index, two queries at a time
+    through the same workspaces, nothing synchronised in between; every answer must be the one a lone search gives."""
+    import torch
+    from rag_amd import DeviceIndex
+    rng = np.random.default_rng(29)
+    n, d, k = 300_000, 384, 10
+    X = _unit(rng, n, d)
+    Q = _unit(rng, 48, d)
+    xt = torch.from_numpy(X).cuda()
+    qt = torch.from_numpy(Q).cuda()
+    idx = DeviceIndex(d, metric="ip")
+    idx.adopt(xt)
+    alone = [idx.search(qt[i:i + 2], k) for i in range(0, 48, 2)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.current_stream()]
+    got = []
+    for j, i in enumerate(range(0, 48, 2)):
+        with torch.cuda.stream(streams[(j * 2) % 3 if j % 4 else j % 3]):      # same stream twice in a row now and then
+            got.append(idx.search(qt[i:i + 2], k))
+    torch.cuda.synchronize()
+    for (Da, Ia), (Dg, Ig) in zip(alone, got):
+        assert torch.equal(Ia, Ig) and torch.equal(Da, Dg)
+    _check(got[5][0].cpu().numpy(), got[5][1].cpu().numpy(), X, Q[10:12], k)
+    idx.close()
+
+
 def test_merge_topk_device():
     import torch
     from rag_amd import DeviceIndex, merge_topk
