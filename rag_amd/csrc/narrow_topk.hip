@@ -10,7 +10,8 @@
 // 96 KiB at ld = 768), laid out in MFMA fragment order.  Each wave streams its own contiguous row
 // range with coalesced loads -- one wave instruction fetches 8 rows x 128 contiguous bytes -- into a
 // ring of registers that keeps (NSETS - 1) * DEPTH steps of 32 rows x 32 floats (24 KiB per wave) in
-// flight.  A landed step is turned into MFMA A fragments through a wave-private 4 KiB LDS image
+// flight.  A landed step is turned into MFMA A fragments through a wave-private 4 KiB LDS image (2 KiB, both row groups in
+// turn, where 32 queries x 1024 floats leave no room for more)
 // (ds_write_b128 rows, ds_read_b128 fragments, 16-byte chunks XOR-swizzled by row pair so both
 // are conflict free): lane (i = lane & 15, kq = lane >> 4) receives k = 16 m + 4 kq + v of row i.
 // (Loading the fragments straight from global memory -- 16 rows x 64 bytes per instruction -- caps
@@ -78,6 +79,10 @@ constexpr int NR_MAX_K = 32;
 #ifndef RAG_NARROW_SGB
 #define RAG_NARROW_SGB 4
 #endif
+// measurement knob: 1 = one transposer image per wave for both row groups in every shape (default: only where two do not fit LDS)
+#ifndef RAG_NARROW_TP_HALF
+#define RAG_NARROW_TP_HALF 0
+#endif
 
 struct NarrowArgs {
     const float* X;
@@ -111,15 +116,18 @@ struct AChunk {
 // groups per row (ld / (16 * DEPTH)) is a multiple of NSETS, so every tile starts with the same rotation.
 // STORE: every score goes to a.scores and nothing is selected (no candidate buffers, thresholds or partial lists): what a
 // batch of up to 32 queries that asks for more keys than the selection carries runs per group of segments.
-template <int NJ, int DEPTH, int NSETS, bool STORE = false>
+// TPH: one 2 KiB transposer image per wave serves both row groups in turn (two images: 3-4 % faster, taken wherever they fit;
+// with one, a block of 32 queries x 1024 floats fits LDS and such batches leave the 256 x 32 GEMM shape: 7.4 -> 6.9 ms at 10M rows)
+template <int NJ, int DEPTH, int NSETS, bool STORE = false, bool TPH = false>
 __global__ __launch_bounds__(NR_WAVES * 64, NR_WAVES / 4) void narrow_topk_kernel(NarrowArgs a) {
+    constexpr int NR_TP_F4 = TPH ? 128 : 256;           // f4 slots of a wave's transposer
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (a.run_if && *a.run_if == 0) return;
     constexpr int NQB = NJ * 16;                        // queries of the block
     const int G = a.ld / 16;                            // K chunks per row
     f4* Qs = reinterpret_cast<f4*>(smem);               // [G][NJ][64] fragment order
     f4* stage = Qs + (size_t)G * NJ * 64;               // [waves][2 row groups][16 rows][8] transposer images (4 KiB per wave)
-    float* s_thr = reinterpret_cast<float*>(stage + NR_WAVES * 256);     // [waves][NQB]
+    float* s_thr = reinterpret_cast<float*>(stage + NR_WAVES * NR_TP_F4);     // [waves][NQB]
     int* s_cnt = reinterpret_cast<int*>(s_thr + NR_WAVES * NQB);         // [waves][NQB]
     int* s_flag = s_cnt + NR_WAVES * NQB;                                // [waves]
 
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(NR_WAVES * 64, NR_WAVES / 4) void narrow_topk_kerne
     int* my_cnt = s_cnt + wave * NQB;
     u64* my_cand = a.cand + (size_t)w * NQB * NR_CAP;
     // the wave's transposer: [row group][16 rows][8 chunks of 16 bytes], chunk c of row r at position c ^ ((r >> 1) & 7)
-    f4* tp = stage + (size_t)wave * 256;
+    f4* tp = stage + (size_t)wave * NR_TP_F4;
     const int lrow = lane >> 3, lchunk = lane & 7;      // as loaded: row within an 8-row half, 16-byte chunk
     int wr_off[2], rd_off[2];                           // f4 units inside one row group's image
 #pragma unroll
@@ -224,6 +232,17 @@ __global__ __launch_bounds__(NR_WAVES * 64, NR_WAVES / 4) void narrow_topk_kerne
         // operations complete in issue order, so the image can be reused at once)
         f4 af[2][2][2], bq[2][2][NJ];                   // [parity][row group][m], [parity][m][query column]
         auto transpose = [&](const AChunk& c, int par) {
+            if constexpr (TPH) {
+                // one 2 KiB image for both row groups, one after the other (a wave's LDS operations complete in issue order)
+#pragma unroll
+                for (int rg = 0; rg < 2; ++rg) {
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) tp[wr_off[hh]] = c.r[rg][hh];
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) af[par][rg][m] = tp[rd_off[m]];
+                }
+                return;
+            }
 #pragma unroll
             for (int rg = 0; rg < 2; ++rg)
 #pragma unroll
@@ -495,9 +514,11 @@ static int env_int_n(const char* name, int dflt) {
     return (v && *v) ? atoi(v) : dflt;
 }
 
-static size_t narrow_lds_bytes(int ld, int nj) {
-    return (size_t)ld * nj * 16 * sizeof(float) + (size_t)NR_WAVES * 4096 + (size_t)NR_WAVES * nj * 16 * 8 + NR_WAVES * 4 + 16;
+static size_t narrow_lds_bytes(int ld, int nj, bool tph = false) {
+    return (size_t)ld * nj * 16 * sizeof(float) + (size_t)NR_WAVES * (tph ? 2048 : 4096) + (size_t)NR_WAVES * nj * 16 * 8 + NR_WAVES * 4 + 16;
 }
+// the selecting kernel's transposers: two images per wave where they fit beside the query block, else one
+static bool narrow_tp_half(int ld, int nj) { return RAG_NARROW_TP_HALF || narrow_lds_bytes(ld, nj, false) > 160 * 1024; }
 
 static int narrow_grid(long long rows) {
     static const int grid_env = env_int_n("RAG_NARROW_WGS", 0);          // measurement only
@@ -539,7 +560,8 @@ bool narrow_topk_supported(const rag_index* h, long long nq, int k) {
     static const int min_nq = env_int_n("RAG_GEMM_MIN_NQ", 5);
     if (!on || h->kind != RAG_KIND_FLAT || nq < min_nq || nq > 32 || k > NR_MAX_K || h->n < 4096) return false;
     if ((h->ld % 128) != 0) return false;
-    return narrow_lds_bytes(h->ld, nq <= 16 ? 1 : 2) <= 160 * 1024;
+    const int nj = nq <= 16 ? 1 : 2;
+    return narrow_lds_bytes(h->ld, nj, narrow_tp_half(h->ld, nj)) <= 160 * 1024;
 }
 
 size_t narrow_topk_workspace(const rag_index* h, long long nq, int k) {
@@ -547,24 +569,29 @@ size_t narrow_topk_workspace(const rag_index* h, long long nq, int k) {
     return p.cand_bytes + p.part_bytes + p.tmp_bytes + 256;
 }
 
-template <int NJ, int DEPTH, int NSETS>
+template <int NJ, int DEPTH, int NSETS, bool TPH>
 static int launch_narrow(const NarrowArgs& a, int grid, size_t lds, int device, hipStream_t s) {
     static bool attr_set[64] = {};
     if (!attr_set[device & 63]) {
-        RAG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(narrow_topk_kernel<NJ, DEPTH, NSETS>),
+        RAG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(narrow_topk_kernel<NJ, DEPTH, NSETS, false, TPH>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set[device & 63] = true;
     }
-    hipLaunchKernelGGL((narrow_topk_kernel<NJ, DEPTH, NSETS>), dim3(grid), dim3(NR_WAVES * 64), lds, s, a);
+    hipLaunchKernelGGL((narrow_topk_kernel<NJ, DEPTH, NSETS, false, TPH>), dim3(grid), dim3(NR_WAVES * 64), lds, s, a);
     RAG_HIP_CHECK(hipGetLastError());
     return RAG_OK;
 }
 
-static int launch_narrow_shape(const NarrowArgs& a, int nj, int grid, size_t lds, int device, hipStream_t s) {
+template <bool TPH>
+static int launch_narrow_tp(const NarrowArgs& a, int nj, int grid, size_t lds, int device, hipStream_t s) {
     // 4 register sets of 2 K steps where a row holds a multiple of 8 steps (ld % 256 == 0), of 1 step otherwise
     const bool wide = (a.ld % 256) == 0;
-    if (nj == 1) return wide ? launch_narrow<1, RAG_NARROW_DEPTH1, 4>(a, grid, lds, device, s) : launch_narrow<1, 1, 4>(a, grid, lds, device, s);
-    return wide ? launch_narrow<2, RAG_NARROW_DEPTH2, RAG_NARROW_NSETS2>(a, grid, lds, device, s) : launch_narrow<2, 1, 4>(a, grid, lds, device, s);
+    if (nj == 1) return wide ? launch_narrow<1, RAG_NARROW_DEPTH1, 4, TPH>(a, grid, lds, device, s) : launch_narrow<1, 1, 4, TPH>(a, grid, lds, device, s);
+    return wide ? launch_narrow<2, RAG_NARROW_DEPTH2, RAG_NARROW_NSETS2, TPH>(a, grid, lds, device, s) : launch_narrow<2, 1, 4, TPH>(a, grid, lds, device, s);
+}
+
+static int launch_narrow_shape(const NarrowArgs& a, int nj, int grid, size_t lds, int device, hipStream_t s) {
+    return narrow_tp_half(a.ld, nj) ? launch_narrow_tp<true>(a, nj, grid, lds, device, s) : launch_narrow_tp<false>(a, nj, grid, lds, device, s);
 }
 
 // The score-writing variant for the segment walk: up to 32 queries against `rows` rows starting at X, every score to
@@ -632,7 +659,7 @@ int narrow_topk_search(rag_index* h, long long nq, const float* qbuf, int k, flo
     a.ld = h->ld;
     a.k = k;
     RAG_HIP_CHECK(hipMemsetAsync(a.gthr, 0, 256, s));
-    const size_t lds = narrow_lds_bytes(h->ld, nj);
+    const size_t lds = narrow_lds_bytes(h->ld, nj, narrow_tp_half(h->ld, nj));
     MergeArgs m = {};
     m.keys = a.part;
     m.stride = (long long)a.W_total * k;

@@ -11,7 +11,8 @@ def flat_fp32_path(n, d, nq, k):
         return "gemm-scores"          # every score written by the matrix-core kernel, one selection workgroup per query
     if 5 <= nq <= 32 and k <= 32 and n >= 4096 and ld % 128 == 0:
         nj = 1 if nq <= 16 else 2
-        if ld * nj * 64 + 8 * 4096 + 8 * nj * 16 * 8 + 48 <= 160 * 1024:
+        # (two 2 KiB transposer images per wave where they fit beside the query block, else one)
+        if ld * nj * 64 + 8 * 2048 + 8 * nj * 16 * 8 + 48 <= 160 * 1024:
             return "narrow"
     if nq >= 5 and k <= 64 and ld % 32 == 0 and n >= 1:
         return "gemm"

@@ -236,6 +236,34 @@ def test_seeded_thresholds_on_adversarial_order(nq, k):
     idx.close()
 
 
+@pytest.mark.parametrize("n,nq,k", [(60_000, 17, 10), (60_000, 32, 32), (300_000, 24, 10), (40_000, 16, 10)])
+def test_narrow_kernel_on_rows_of_1024_floats(n, nq, k):
+    """32 queries x 1024 floats fill 128 KiB of LDS: the kernel then keeps one transposer image per wave for both row
+    groups instead of two (17..32 queries; up to 16 queries keep two).  Near ties, duplicates, a mask, a threshold."""
+    from rag_amd import DeviceIndex
+    rng = np.random.default_rng(n + nq)
+    d = 1024
+    X = _unit(rng, n, d)
+    Q = _unit(rng, nq, d)
+    X[n // 2: n // 2 + 6] = X[9]
+    Q[1] = X[9]
+    X[100:130] = X[77] * np.float32(0.9995)
+    Q[2] = X[77]
+    idx = DeviceIndex(d, metric="ip")
+    idx.add(X)
+    D, I = idx.search(Q, k)
+    assert idx.last_path == "narrow"
+    _check(D, I, X, Q, k)
+    if k >= 7:
+        assert I[1, :7].tolist() == [9] + list(range(n // 2, n // 2 + 6))
+    mask = (rng.uniform(size=n) < 0.4).astype(np.uint8)
+    D, I = idx.search(Q, k, row_mask=mask, min_score=0.05)
+    _check(D, I, X, Q, k, row_mask=mask, min_score=0.05)
+    rows = [idx.search(Q[i], k) for i in (0, nq - 1)]
+    assert np.array_equal(np.concatenate([r[1] for r in rows]), idx.search(Q, k)[1][[0, nq - 1]])
+    idx.close()
+
+
 @pytest.mark.parametrize("nq,k", [(7, 10), (16, 32), (32, 10), (20, 1)])
 def test_narrow_kernel_with_sample_launch(nq, k):
     """5..32 queries on 2^20+ rows: the register-streaming kernel starts from thresholds its first launch took from the
